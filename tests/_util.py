@@ -1,0 +1,55 @@
+"""Helpers shared by the test modules: golden loading and tolerant comparisons."""
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_npz(name):
+    with np.load(os.path.join(GOLDEN, name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+def load_inputs(name):
+    """inputs_<name>.npz -> the argument structure of the reference's loss calls (torch, CPU)."""
+    z = load_npz(f"inputs_{name}.npz")
+    n_ref = sum(1 for k in z if k.startswith("ref_img"))
+    n_scales = sum(1 for k in z if k.startswith("tgt_depth_s"))
+    t = lambda k: torch.from_numpy(z[k])
+    return {
+        "tgt_img": t("tgt_img"),
+        "ref_imgs": [t(f"ref_img{i}") for i in range(n_ref)],
+        "intrinsics": t("K"),
+        "tgt_depth": [t(f"tgt_depth_s{s}") for s in range(n_scales)],
+        "ref_depths": [[t(f"ref{i}_depth_s{s}") for s in range(n_scales)] for i in range(n_ref)],
+        "poses": [t(f"pose{i}") for i in range(n_ref)],
+        "poses_inv": [t(f"pose_inv{i}") for i in range(n_ref)],
+    }
+
+
+def probe(n):
+    return torch.cos(0.37 * torch.arange(n, dtype=torch.float64))
+
+
+def grad_stats(g):
+    f = g.detach().double().reshape(-1).cpu()
+    return np.array([f.sum().item(), f.abs().sum().item(), (f * probe(f.numel())).sum().item()])
+
+
+def leaf(t):
+    return t.clone().requires_grad_(True)
+
+
+def assert_close_frac(a, b, atol, rtol=0.0, max_bad_frac=0.0, what=""):
+    """|a-b| <= atol + rtol*|b| for all but a fraction ``max_bad_frac`` of the entries.  The
+    fraction allows for the discontinuous gates of the path (valid / auto mask, clamps): a 1-ulp
+    difference in a coordinate can flip a pixel."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    bad = np.abs(a - b) > (atol + rtol * np.abs(b))
+    frac = bad.mean() if bad.size else 0.0
+    assert frac <= max_bad_frac, f"{what}: {bad.sum()} of {bad.size} entries differ (max |d|={np.abs(a-b).max():.3e})"

@@ -1,0 +1,120 @@
+"""The CPU oracle (oracle/scsfm_oracle.py) must reproduce every golden fixture that
+oracle/make_golden.py recorded from the unmodified reference (fp32, torch CPU)."""
+import numpy as np
+import pytest
+import torch
+
+from _util import assert_close_frac, grad_stats, leaf, load_inputs, load_npz
+from oracle import scsfm_oracle as O
+
+FLAGS = [(1, 1, 1), (1, 1, 0), (1, 0, 1), (1, 0, 0), (0, 1, 1), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
+FULL = {"111_zeros", "110_border", "010_zeros"}
+
+
+@pytest.mark.parametrize("impl", ["explicit", "aten"])
+@pytest.mark.parametrize("name", ["smooth", "iid", "tiny"])
+def test_pairwise_loss_and_grads(name, impl):
+    d = load_inputs(name)
+    gold = load_npz(f"pair_{name}.npz")
+    for ssim, mask, auto in FLAGS:
+        for pad in ("zeros", "border"):
+            key = f"{ssim}{mask}{auto}_{pad}"
+            dt, dr, pose = leaf(d["tgt_depth"][0]), leaf(d["ref_depths"][0][0]), leaf(d["poses"][0])
+            photo, geom = O.pairwise_loss(d["tgt_img"], d["ref_imgs"][0], dt, dr, pose, d["intrinsics"],
+                                          ssim, mask, auto, pad, impl=impl)
+            tol = 5e-7 if impl == "aten" else 2e-6  # reduction order depends on the thread count
+            assert abs(float(photo.detach()) - float(gold[f"{key}/photo"])) <= tol, key
+            assert abs(float(geom.detach()) - float(gold[f"{key}/geom"])) <= tol, key
+            L = 1.0 * photo + 0.5 * geom
+            if not L.requires_grad:
+                assert name == "tiny"
+                assert float(gold[f"{key}/photo"]) == 0.0 or float(gold[f"{key}/geom"]) == 0.0
+                continue
+            L.backward()
+            gp = pose.grad if pose.grad is not None else torch.zeros_like(pose)
+            assert_close_frac(gp.numpy(), gold[f"{key}/g_pose"], atol=1e-5, rtol=1e-4, what=key + " g_pose")
+            for nm, t in (("g_tgt_depth", dt), ("g_ref_depth", dr)):
+                g = t.grad if t.grad is not None else torch.zeros_like(t)
+                st = gold[f"{key}/{nm}_stats"]
+                mine = grad_stats(g)
+                assert abs(mine[1] - st[1]) <= 1e-4 * st[1] + 1e-9, (key, nm, mine, st)
+                assert abs(mine[2] - st[2]) <= 1e-4 * st[1] + 1e-9, (key, nm, mine, st)
+                if key in FULL:
+                    assert_close_frac(g.numpy(), gold[f"{key}/{nm}"], atol=2e-8, rtol=1e-4,
+                                      max_bad_frac=1e-3, what=f"{key} {nm}")
+
+
+@pytest.mark.parametrize("impl", ["explicit", "aten"])
+@pytest.mark.parametrize("name", ["smooth", "iid"])
+def test_warp_maps(name, impl):
+    d = load_inputs(name)
+    gold = load_npz(f"maps_{name}.npz")
+    for pad in ("zeros", "border"):
+        w, v, pd, cd = O.inverse_warp2(d["ref_imgs"][0], d["tgt_depth"][0], d["ref_depths"][0][0],
+                                       d["poses"][0], d["intrinsics"], pad, impl=impl)
+        bad = 0.0 if impl == "aten" else 1e-3
+        assert (v.numpy().astype(np.uint8) != gold[f"{pad}/valid_mask"]).mean() <= bad
+        assert_close_frac(w.numpy(), gold[f"{pad}/projected_img"], atol=2e-5, max_bad_frac=bad, what="img")
+        assert_close_frac(pd.numpy(), gold[f"{pad}/projected_depth"], atol=1e-5, rtol=1e-5, max_bad_frac=bad,
+                          what="proj depth")
+        assert_close_frac(cd.numpy(), gold[f"{pad}/computed_depth"], atol=1e-5, rtol=1e-5, what="comp depth")
+
+
+@pytest.mark.parametrize("name", ["smooth", "iid"])
+def test_total_loss_and_grads(name):
+    d = load_inputs(name)
+    gold = load_npz(f"total_{name}.npz")
+    for n_scales in (1, 2):
+        for ssim, mask, auto, pad in ((1, 1, 1, "zeros"), (1, 1, 0, "border")):
+            key = f"s{n_scales}_{ssim}{mask}{auto}_{pad}"
+            td = [leaf(x) for x in d["tgt_depth"]]
+            rd = [[leaf(x) for x in r] for r in d["ref_depths"]]
+            ps = [leaf(p) for p in d["poses"]]
+            pi = [leaf(p) for p in d["poses_inv"]]
+            photo, geom = O.photo_and_geometry_loss(d["tgt_img"], d["ref_imgs"], d["intrinsics"], td, rd, ps, pi,
+                                                    n_scales, ssim, mask, auto, pad)
+            smooth = O.smooth_loss(td, d["tgt_img"], rd, d["ref_imgs"])
+            assert abs(float(photo.detach()) - float(gold[f"{key}/photo"])) <= 5e-6
+            assert abs(float(geom.detach()) - float(gold[f"{key}/geom"])) <= 5e-6
+            assert abs(float(smooth.detach()) - float(gold[f"{key}/smooth"])) <= 5e-6
+            (1.0 * photo + 0.1 * smooth + 0.5 * geom).backward()
+            for s in range(2):
+                g = td[s].grad if td[s].grad is not None else torch.zeros_like(td[s])
+                assert_close_frac(g.numpy(), gold[f"{key}/g_tgt_depth_s{s}"], atol=5e-8, rtol=1e-4,
+                                  max_bad_frac=1e-3, what=f"{key} tgt s{s}")
+                for i in range(2):
+                    g = rd[i][s].grad if rd[i][s].grad is not None else torch.zeros_like(rd[i][s])
+                    assert_close_frac(g.numpy(), gold[f"{key}/g_ref{i}_depth_s{s}"], atol=5e-8, rtol=1e-4,
+                                      max_bad_frac=1e-3, what=f"{key} ref{i} s{s}")
+            for i in range(2):
+                assert_close_frac(ps[i].grad.numpy(), gold[f"{key}/g_pose{i}"], atol=2e-5, rtol=1e-4)
+                assert_close_frac(pi[i].grad.numpy(), gold[f"{key}/g_pose_inv{i}"], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["smooth", "iid"])
+def test_smooth_only(name):
+    d = load_inputs(name)
+    gold = load_npz(f"total_{name}.npz")
+    td = [leaf(x) for x in d["tgt_depth"]]
+    rd = [[leaf(x) for x in r] for r in d["ref_depths"]]
+    loss = O.smooth_loss(td, d["tgt_img"], rd, d["ref_imgs"])
+    loss.backward()
+    assert abs(float(loss.detach()) - float(gold["smooth_only/loss"])) <= 1e-6
+    assert_close_frac(td[0].grad.numpy(), gold["smooth_only/g_tgt_depth"], atol=1e-9, rtol=1e-4)
+    for i in range(2):
+        assert_close_frac(rd[i][0].grad.numpy(), gold[f"smooth_only/g_ref{i}_depth"], atol=1e-9, rtol=1e-4)
+
+
+def test_pose_and_errors():
+    gold = load_npz("misc.npz")
+    vec = torch.from_numpy(gold["pose/vec"])
+    r = torch.from_numpy(gold["pose/probe"])
+    for mode in ("euler", "quat"):
+        v = leaf(vec)
+        M = O.pose_vec2mat(v, mode)
+        (M * r).sum().backward()
+        np.testing.assert_allclose(M.detach().numpy(), gold[f"pose/{mode}/mat"], atol=1e-6)
+        np.testing.assert_allclose(v.grad.numpy(), gold[f"pose/{mode}/g_vec"], atol=2e-6)
+    for ds in ("kitti", "nyu"):
+        out = O.depth_errors(torch.from_numpy(gold[f"errors/{ds}/gt"]), torch.from_numpy(gold[f"errors/{ds}/pred"]), ds)
+        np.testing.assert_allclose(out, gold[f"errors/{ds}/out"], rtol=1e-6, atol=1e-7)

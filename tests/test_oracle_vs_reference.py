@@ -1,0 +1,69 @@
+"""Live cross-check of the oracle against the unmodified reference, whenever /root/reference is
+mounted (the build container).  Skipped on the GPU box, where only the goldens travel."""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+
+from _util import leaf
+from oracle import scsfm_oracle as O
+from scsfm_hip import synth
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    try:
+        # our package mirrors the reference's module names; make sure the reference's own win here
+        for m in ("inverse_warp", "loss_functions"):
+            sys.modules.pop(m, None)
+        rw = importlib.import_module("inverse_warp")
+        rl = importlib.import_module("loss_functions")
+        assert rw.__file__.startswith(REF) and rl.__file__.startswith(REF)
+        yield rl, rw
+    finally:
+        sys.path.remove(REF)
+        for m in ("inverse_warp", "loss_functions"):
+            sys.modules.pop(m, None)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-6), (torch.float64, 1e-12)])
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_total_loss_matches_reference(ref, dtype, tol, pad):
+    rl, _ = ref
+    d = synth.make_batch(2, 72, 104, n_ref=2, seed=11, depth="smooth", num_scales=2)
+    cast = lambda x: x.to(dtype)
+    args = dict(tgt_img=cast(d["tgt_img"]), ref_imgs=[cast(x) for x in d["ref_imgs"]], K=cast(d["intrinsics"]))
+
+    def run(fn_pg, fn_s):
+        td = [leaf(cast(x)) for x in d["tgt_depth"]]
+        rd = [[leaf(cast(x)) for x in r] for r in d["ref_depths"]]
+        ps = [leaf(cast(p)) for p in d["poses"]]
+        pi = [leaf(cast(p)) for p in d["poses_inv"]]
+        photo, geom = fn_pg(args["tgt_img"], args["ref_imgs"], args["K"], td, rd, ps, pi, 2, 1, 1, 1, pad)
+        smooth = fn_s(td, args["tgt_img"], rd, args["ref_imgs"])
+        (photo + 0.1 * smooth + 0.5 * geom).backward()
+        grads = [t.grad for t in td] + [t.grad for r in rd for t in r] + [p.grad for p in ps + pi]
+        return [photo.detach(), geom.detach(), smooth.detach()], grads
+
+    vr, gr = run(rl.compute_photo_and_geometry_loss, rl.compute_smooth_loss)
+    vo, go = run(O.photo_and_geometry_loss, O.smooth_loss)
+    for a, b in zip(vr, vo):
+        assert abs(float(a) - float(b)) <= tol
+    for a, b in zip(gr, go):
+        scale = float(a.abs().max()) + 1e-30
+        bad = ((a - b).abs() > 1e-3 * scale * (1 if dtype == torch.float32 else 1e-7)).double().mean()
+        assert bad <= (1e-3 if dtype == torch.float32 else 0.0)
+
+
+def test_pose_modes_match_reference(ref):
+    _, rw = ref
+    v = torch.randn(7, 6, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    for mode in ("euler", "quat"):
+        assert (rw.pose_vec2mat(v, mode) - O.pose_vec2mat(v, mode)).abs().max() < 1e-14
