@@ -36,7 +36,8 @@ def ref():
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-6), (torch.float64, 1e-12)])
 @pytest.mark.parametrize("pad", ["zeros", "border"])
 def test_total_loss_matches_reference(ref, dtype, tol, pad):
-    rl, _ = ref
+    rl, rw = ref
+    rw.pixel_coords = None  # the reference caches its pixel grid (and its dtype) module-globally, inverse_warp.py:5,39
     d = synth.make_batch(2, 72, 104, n_ref=2, seed=11, depth="smooth", num_scales=2)
     cast = lambda x: x.to(dtype)
     args = dict(tgt_img=cast(d["tgt_img"]), ref_imgs=[cast(x) for x in d["ref_imgs"]], K=cast(d["intrinsics"]))
