@@ -1,0 +1,136 @@
+/*
+ * scsfm_hip.h -- C ABI of libscsfm_hip.so: the SC-SfMLearner warp + loss hot path as hand-written
+ * HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (JiawangBian/SC-SfMLearner-Release) has no FFI layer: its operator API for this
+ * path is a set of Python callables in inverse_warp.py / loss_functions.py.  Each
+ * entry point below replaces the ATen op chain behind one of those callables and is what the
+ * Python shim in sc-sfmlearner-release_amd/{inverse_warp,loss_functions}.py binds through ctypes
+ * (see INTEGRATION.md for the binding a reference maintainer would add).
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers to contiguous NCHW fp32 ("_f32") or fp64 ("_f64", used by the
+ *    gradient-check tests) arrays; the caller owns every buffer; nothing is retained after return.
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no call synchronises.
+ *  - Return value: 0 on success, SCSFM_ERR_ARG for a rejected argument, otherwise the hipError_t of
+ *    the failed launch.  No exceptions cross the ABI.
+ *  - "accumulate" outputs are added to (the caller zeroes them once per step); "store" outputs are
+ *    overwritten.
+ *  - `flags` is a bit set of SCSFM_* below; `with_ssim / with_mask / with_auto_mask / padding_mode`
+ *    of loss_functions.py:50,95 map onto it one to one.
+ */
+#ifndef SCSFM_HIP_H_
+#define SCSFM_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCSFM_WITH_SSIM 1u      /* loss_functions.py:107 */
+#define SCSFM_WITH_MASK 2u      /* loss_functions.py:111 */
+#define SCSFM_WITH_AUTO_MASK 4u /* loss_functions.py:103 */
+#define SCSFM_PAD_BORDER 8u     /* padding_mode == 'border' (default 'zeros'), inverse_warp.py:219-224,262 */
+
+#define SCSFM_ROT_EULER 0 /* inverse_warp.py:77-112  */
+#define SCSFM_ROT_QUAT 1  /* inverse_warp.py:115-136 */
+
+#define SCSFM_OK 0
+#define SCSFM_ERR_ARG (-1)
+
+/* ABI version of this header; bumped on any signature change. */
+int scsfm_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * compute_pairwise_loss (loss_functions.py:95-119) incl. inverse_warp2 (inverse_warp.py:230-269),
+ * SSIM (loss_functions.py:11-42) and mean_on_mask (loss_functions.py:123-129), one (tgt, ref)
+ * pair-direction.
+ *
+ * scsfm_pair_ws_bytes : size of the per-call device workspace `ws`.  The same `ws` must be handed,
+ *                       untouched, from scsfm_pair_fwd to the matching scsfm_pair_bwd.
+ * scsfm_pair_fwd      : out[4] (device, store) = { photo_loss, geometry_loss, sum(mask), 0 }.
+ *                       The 10000-pixel gate of mean_on_mask is evaluated on the device: a gated-off
+ *                       term is 0 and produces zero gradients (no host sync, unlike the reference).
+ * scsfm_pair_bwd      : g_photo / g_geom are device scalars (upstream gradients of the two losses).
+ *                       g_tgt_depth [B,1,H,W] accumulate (dense), g_ref_depth [B,1,H,W] accumulate
+ *                       (atomic scatter of the bilinear taps), g_pose [B,6] store.
+ * --------------------------------------------------------------------------------------------- */
+size_t scsfm_pair_ws_bytes(int B, int H, int W);
+
+int scsfm_pair_fwd_f32(int B, int H, int W, const float* tgt_img, const float* ref_img,
+                       const float* tgt_depth, const float* ref_depth, const float* pose,
+                       const float* intrinsics, unsigned flags, void* ws, float* out, void* stream);
+int scsfm_pair_bwd_f32(int B, int H, int W, const float* tgt_img, const float* ref_img,
+                       const float* tgt_depth, const float* ref_depth, const float* pose,
+                       const float* intrinsics, unsigned flags, void* ws, const float* g_photo,
+                       const float* g_geom, float* g_tgt_depth, float* g_ref_depth, float* g_pose,
+                       void* stream);
+int scsfm_pair_fwd_f64(int B, int H, int W, const double* tgt_img, const double* ref_img,
+                       const double* tgt_depth, const double* ref_depth, const double* pose,
+                       const double* intrinsics, unsigned flags, void* ws, double* out, void* stream);
+int scsfm_pair_bwd_f64(int B, int H, int W, const double* tgt_img, const double* ref_img,
+                       const double* tgt_depth, const double* ref_depth, const double* pose,
+                       const double* intrinsics, unsigned flags, void* ws, const double* g_photo,
+                       const double* g_geom, double* g_tgt_depth, double* g_ref_depth,
+                       double* g_pose, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * inverse_warp2 (inverse_warp.py:230-269) as maps: projected_img [B,3,H,W], valid_mask [B,1,H,W]
+ * (0/1), projected_depth [B,1,H,W], computed_depth [B,1,H,W] (all store).  The backward takes the
+ * upstream gradients of the three differentiable maps (any may be NULL) and produces g_depth
+ * (accumulate), g_ref_depth (accumulate, atomic scatter), g_pose [B,6] (store).  `ws` needs
+ * scsfm_warp_ws_bytes(B) bytes.  Only SCSFM_PAD_BORDER is read from `flags`.
+ * --------------------------------------------------------------------------------------------- */
+size_t scsfm_warp_ws_bytes(int B);
+
+int scsfm_warp_fwd_f32(int B, int H, int W, const float* img, const float* depth,
+                       const float* ref_depth, const float* pose, const float* intrinsics,
+                       unsigned flags, void* ws, float* projected_img, float* valid_mask,
+                       float* projected_depth, float* computed_depth, void* stream);
+int scsfm_warp_bwd_f32(int B, int H, int W, const float* img, const float* depth,
+                       const float* ref_depth, const float* pose, const float* intrinsics,
+                       unsigned flags, void* ws, const float* g_projected_img,
+                       const float* g_projected_depth, const float* g_computed_depth,
+                       float* g_depth, float* g_ref_depth, float* g_pose, void* stream);
+int scsfm_warp_fwd_f64(int B, int H, int W, const double* img, const double* depth,
+                       const double* ref_depth, const double* pose, const double* intrinsics,
+                       unsigned flags, void* ws, double* projected_img, double* valid_mask,
+                       double* projected_depth, double* computed_depth, void* stream);
+int scsfm_warp_bwd_f64(int B, int H, int W, const double* img, const double* depth,
+                       const double* ref_depth, const double* pose, const double* intrinsics,
+                       unsigned flags, void* ws, const double* g_projected_img,
+                       const double* g_projected_depth, const double* g_computed_depth,
+                       double* g_depth, double* g_ref_depth, double* g_pose, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * pose_vec2mat (inverse_warp.py:139-154): vec [B,6] = (tx,ty,tz,rx,ry,rz) -> mat [B,3,4] (store);
+ * backward: g_mat [B,3,4] -> g_vec [B,6] (store).  mode = SCSFM_ROT_EULER | SCSFM_ROT_QUAT.
+ * --------------------------------------------------------------------------------------------- */
+int scsfm_pose_vec2mat_fwd_f32(int B, const float* vec, int mode, float* mat, void* stream);
+int scsfm_pose_vec2mat_bwd_f32(int B, const float* vec, int mode, const float* g_mat, float* g_vec,
+                               void* stream);
+int scsfm_pose_vec2mat_fwd_f64(int B, const double* vec, int mode, double* mat, void* stream);
+int scsfm_pose_vec2mat_bwd_f64(int B, const double* vec, int mode, const double* g_mat,
+                               double* g_vec, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * get_smooth_loss of compute_smooth_loss (loss_functions.py:132-152), one frame:
+ * depth [B,1,H,W], img [B,3,H,W] -> out[1] (device, store).  Backward: g_loss device scalar,
+ * g_depth accumulate.  `ws` (scsfm_smooth_ws_bytes) carries the per-image sums fwd -> bwd.
+ * --------------------------------------------------------------------------------------------- */
+size_t scsfm_smooth_ws_bytes(int B, int H, int W);
+
+int scsfm_smooth_fwd_f32(int B, int H, int W, const float* depth, const float* img, void* ws,
+                         float* out, void* stream);
+int scsfm_smooth_bwd_f32(int B, int H, int W, const float* depth, const float* img, void* ws,
+                         const float* g_loss, float* g_depth, void* stream);
+int scsfm_smooth_fwd_f64(int B, int H, int W, const double* depth, const double* img, void* ws,
+                         double* out, void* stream);
+int scsfm_smooth_bwd_f64(int B, int H, int W, const double* depth, const double* img, void* ws,
+                         const double* g_loss, double* g_depth, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCSFM_HIP_H_ */

@@ -1,0 +1,116 @@
+// Shared device-side definitions for the SC-SfMLearner warp + loss kernels (gfx950).
+//
+// Math spec: SURVEY.md §9; reference lines are cited next to each function.  Everything is
+// templated on the scalar type T: float is the product path, double exists for the
+// gradient-check tests (exported as the *_f64 entry points).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/scsfm_hip.h"
+
+namespace scsfm {
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kThreads = 256;    // 4 waves per workgroup, one per SIMD
+constexpr int kTileW = 64;       // one wave covers one 64-pixel row segment: 256 B coalesced rows
+constexpr int kTileH = 16;       // each thread owns a 4-row column strip
+constexpr int kStrip = 4;
+constexpr int kHaloW = kTileW + 2;
+constexpr int kHaloH = kTileH + 2;
+// backward: the 64x16 compute domain overlaps its neighbours by one pixel on every side, so the
+// interior that a block writes is 62x14 (SSIM backward needs the forward statistics of the ring).
+constexpr int kBwdOutW = kTileW - 2;
+constexpr int kBwdOutH = kTileH - 2;
+
+constexpr double kSsimC1 = 0.01 * 0.01;  // loss_functions.py:25
+constexpr double kSsimC2 = 0.03 * 0.03;  // loss_functions.py:26
+constexpr double kMaskGate = 10000.0;    // loss_functions.py:125
+constexpr double kZMin = 1e-3;           // inverse_warp.py:211
+
+// Per batch element constants written by prep_kernel: K^-1 (inverse_warp.py:253), A|c = K @ [R|t]
+// (inverse_warp.py:258-260).  24 scalars so that consecutive elements stay 32/64-byte aligned and
+// a block can fetch its element with scalar loads (the address is workgroup-uniform).
+template <typename T>
+struct BatchConsts {
+  T Kinv[9];
+  T A[9];
+  T c[3];
+  T pad[3];
+};
+
+// Workspace layout of one pair-direction call (scsfm_pair_ws_bytes).
+//   [0]                consts   : B x BatchConsts<double>-sized slots (T = float uses the front)
+//   [off_sums]         sums     : double[8] = {S_photo, S_geom, S_m, photo, geom, a, b, -}
+//   [off_gP]           gP       : double[B][12]   (gradient of A|c, accumulated with fp64 atomics)
+//   [off_partials]     partials : double[nblocks][3]
+struct PairWs {
+  size_t off_sums, off_gP, off_partials, total;
+  int nbx, nby;
+};
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+inline PairWs pair_ws_layout(int B, int H, int W) {
+  PairWs l;
+  l.nbx = ceil_div(W, kTileW);
+  l.nby = ceil_div(H, kTileH);
+  size_t off = (size_t)B * sizeof(BatchConsts<double>);
+  l.off_sums = off; off += 8 * sizeof(double);
+  l.off_gP = off; off += (size_t)B * 12 * sizeof(double);
+  l.off_partials = off; off += (size_t)l.nbx * l.nby * B * 3 * sizeof(double);
+  l.total = (off + 255) & ~(size_t)255;
+  return l;
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave / block reductions (wave = 64 lanes).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Sum N doubles per thread over the whole block; result valid in thread 0.  `scratch` must hold
+// N * (kThreads / kWave) doubles.
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double* scratch) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double s = wave_sum(v[i]);
+    if (lane == 0) scratch[wave * N + i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double s = 0;
+      for (int w = 0; w < kThreads / kWave; ++w) s += scratch[w * N + i];
+      v[i] = s;
+    }
+  }
+}
+
+__device__ __forceinline__ int reflect_index(int i, int n) {
+  // ReflectionPad2d(1) index map (pad[-1] = x[1], pad[n] = x[n-2]); clamped so that positions
+  // further out (partial tiles) stay addressable -- their values are never used.
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
+template <typename T> __device__ __forceinline__ T t_abs(T x) { return x < T(0) ? -x : x; }
+template <typename T> __device__ __forceinline__ T t_min(T a, T b) { return a < b ? a : b; }
+template <typename T> __device__ __forceinline__ T t_max(T a, T b) { return a > b ? a : b; }
+template <typename T> __device__ __forceinline__ T t_sgn(T x) { return x > T(0) ? T(1) : (x < T(0) ? T(-1) : T(0)); }
+__device__ __forceinline__ float t_floor(float x) { return floorf(x); }
+__device__ __forceinline__ double t_floor(double x) { return floor(x); }
+__device__ __forceinline__ float t_exp(float x) { return expf(x); }
+__device__ __forceinline__ double t_exp(double x) { return exp(x); }
+__device__ __forceinline__ void t_sincos(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
+__device__ __forceinline__ void t_sincos(double x, double* s, double* c) { *s = sin(x); *c = cos(x); }
+__device__ __forceinline__ float t_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double t_sqrt(double x) { return sqrt(x); }
+
+}  // namespace scsfm

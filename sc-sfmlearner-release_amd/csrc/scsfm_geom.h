@@ -1,0 +1,241 @@
+// Camera geometry shared by every kernel: SE(3) pose (inverse_warp.py:77-154), back-projection
+// (inverse_warp.py:29-44), projection (inverse_warp.py:194-227) and the bilinear sampling
+// coordinates of ATen's grid_sampler_2d as the reference calls it (inverse_warp.py:262,267:
+// bilinear, align_corners=False, zeros|border).
+#pragma once
+#include "scsfm_common.h"
+
+namespace scsfm {
+
+// ------------------------------------------------------------------------------------------
+// Rotations.  R is row-major r[3*i+j].
+// ------------------------------------------------------------------------------------------
+// R = Rx(rx) Ry(ry) Rz(rz) in closed form (the reference multiplies the three matrices).
+template <typename T>
+__device__ __forceinline__ void euler_to_R(T rx, T ry, T rz, T* r) {
+  T sx, cx, sy, cy, sz, cz;
+  t_sincos(rx, &sx, &cx);
+  t_sincos(ry, &sy, &cy);
+  t_sincos(rz, &sz, &cz);
+  r[0] = cy * cz;                 r[1] = -cy * sz;                r[2] = sy;
+  r[3] = cx * sz + sx * sy * cz;  r[4] = cx * cz - sx * sy * sz;  r[5] = -sx * cy;
+  r[6] = sx * sz - cx * sy * cz;  r[7] = sx * cz + cx * sy * sz;  r[8] = cx * cy;
+}
+
+// gR (dL/dR) -> dL/d(rx,ry,rz)
+template <typename T>
+__device__ __forceinline__ void euler_bwd(T rx, T ry, T rz, const T* g, T* gang) {
+  T sx, cx, sy, cy, sz, cz;
+  t_sincos(rx, &sx, &cx);
+  t_sincos(ry, &sy, &cy);
+  t_sincos(rz, &sz, &cz);
+  T r[9];
+  euler_to_R(rx, ry, rz, r);
+  // d/drx: rows 1,2 rotate into each other
+  gang[0] = g[3] * (-r[6]) + g[4] * (-r[7]) + g[5] * (-r[8]) + g[6] * r[3] + g[7] * r[4] + g[8] * r[5];
+  gang[1] = g[0] * (-sy * cz) + g[1] * (sy * sz) + g[2] * cy
+          + g[3] * (sx * cy * cz) + g[4] * (-sx * cy * sz) + g[5] * (sx * sy)
+          + g[6] * (-cx * cy * cz) + g[7] * (cx * cy * sz) + g[8] * (-cx * sy);
+  // d/drz: columns 0,1 rotate into each other
+  gang[2] = g[0] * r[1] + g[1] * (-r[0]) + g[3] * r[4] + g[4] * (-r[3]) + g[6] * r[7] + g[7] * (-r[6]);
+}
+
+// inverse_warp.py:115-136: q = (1, x, y, z) / |(1, x, y, z)|
+template <typename T>
+__device__ __forceinline__ void quat_to_R(T qx, T qy, T qz, T* r) {
+  T n = t_sqrt(T(1) + qx * qx + qy * qy + qz * qz);
+  T w = T(1) / n, x = qx / n, y = qy / n, z = qz / n;
+  r[0] = w * w + x * x - y * y - z * z;  r[1] = 2 * x * y - 2 * w * z;          r[2] = 2 * w * y + 2 * x * z;
+  r[3] = 2 * w * z + 2 * x * y;          r[4] = w * w - x * x + y * y - z * z;  r[5] = 2 * y * z - 2 * w * x;
+  r[6] = 2 * x * z - 2 * w * y;          r[7] = 2 * w * x + 2 * y * z;          r[8] = w * w - x * x - y * y + z * z;
+}
+
+template <typename T>
+__device__ __forceinline__ void quat_bwd(T qx, T qy, T qz, const T* g, T* gq3) {
+  T n = t_sqrt(T(1) + qx * qx + qy * qy + qz * qz);
+  T w = T(1) / n, x = qx / n, y = qy / n, z = qz / n;
+  T gw = 2 * (g[0] * w - g[1] * z + g[2] * y + g[3] * z + g[4] * w - g[5] * x - g[6] * y + g[7] * x + g[8] * w);
+  T gx = 2 * (g[0] * x + g[1] * y + g[2] * z + g[3] * y - g[4] * x - g[5] * w + g[6] * z + g[7] * w - g[8] * x);
+  T gy = 2 * (-g[0] * y + g[1] * x + g[2] * w + g[3] * x + g[4] * y + g[5] * z - g[6] * w + g[7] * z - g[8] * y);
+  T gz = 2 * (-g[0] * z - g[1] * w + g[2] * x + g[3] * w - g[4] * z + g[5] * y + g[6] * x + g[7] * y + g[8] * z);
+  // through the normalisation q = u/|u|, u = (1, qx, qy, qz): g_u = (g_q - q <g_q, q>) / |u|
+  T dot = gw * w + gx * x + gy * y + gz * z;
+  gq3[0] = (gx - x * dot) / n;
+  gq3[1] = (gy - y * dot) / n;
+  gq3[2] = (gz - z * dot) / n;
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-batch constants.  One thread per batch element.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void prep_kernel(int B, const T* __restrict__ pose, const T* __restrict__ K,
+                            BatchConsts<T>* __restrict__ out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const T* k = K + 9 * b;
+  // K^-1 by the adjugate, evaluated in fp64 and rounded once (the reference calls
+  // torch.inverse, an LU factorisation; both agree to 1 ulp on camera matrices).
+  double a = k[0], bb = k[1], c = k[2], d = k[3], e = k[4], f = k[5], g = k[6], h = k[7], i = k[8];
+  double C00 = e * i - f * h, C01 = -(d * i - f * g), C02 = d * h - e * g;
+  double det = a * C00 + bb * C01 + c * C02;
+  double inv = 1.0 / det;
+  BatchConsts<T> o;
+  o.Kinv[0] = T(C00 * inv);  o.Kinv[1] = T(-(bb * i - c * h) * inv);  o.Kinv[2] = T((bb * f - c * e) * inv);
+  o.Kinv[3] = T(C01 * inv);  o.Kinv[4] = T((a * i - c * g) * inv);    o.Kinv[5] = T(-(a * f - c * d) * inv);
+  o.Kinv[6] = T(C02 * inv);  o.Kinv[7] = T(-(a * h - bb * g) * inv);  o.Kinv[8] = T((a * e - bb * d) * inv);
+  const T* p = pose + 6 * b;
+  T R[9];
+  euler_to_R(p[3], p[4], p[5], R);  // inverse_warp2 always uses euler angles (inverse_warp.py:255)
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o.A[3 * r + j] = k[3 * r] * R[j] + k[3 * r + 1] * R[3 + j] + k[3 * r + 2] * R[6 + j];
+    o.c[r] = k[3 * r] * p[0] + k[3 * r + 1] * p[1] + k[3 * r + 2] * p[2];
+  }
+  o.pad[0] = o.pad[1] = o.pad[2] = T(0);
+  out[b] = o;
+}
+
+// gP = dL/d(A|c) [B][12] (fp64 accumulators) -> dL/dpose [B,6]:  gT = K^T gP, then the euler chain.
+template <typename T>
+__global__ void pose_bwd_kernel(int B, const T* __restrict__ pose, const T* __restrict__ K,
+                                const double* __restrict__ gP, T* __restrict__ gpose) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const T* k = K + 9 * b;
+  const double* g = gP + 12 * b;
+  T gR[9], gt[3];
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      gR[3 * kk + j] = T(double(k[kk]) * g[j] + double(k[3 + kk]) * g[3 + j] + double(k[6 + kk]) * g[6 + j]);
+    gt[kk] = T(double(k[kk]) * g[9] + double(k[3 + kk]) * g[10] + double(k[6 + kk]) * g[11]);
+  }
+  const T* p = pose + 6 * b;
+  T ga[3];
+  euler_bwd(p[3], p[4], p[5], gR, ga);
+  T* o = gpose + 6 * b;
+  o[0] = gt[0]; o[1] = gt[1]; o[2] = gt[2];
+  o[3] = ga[0]; o[4] = ga[1]; o[5] = ga[2];
+}
+
+// ------------------------------------------------------------------------------------------
+// One target pixel -> where it lands in the reference view.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct Sample {
+  T rx, ry, rz;     // K^-1 (u, v, 1)
+  T X, Y, Zraw, Z;  // A cam + c ; Z = max(Zraw, 1e-3) is the "computed depth"
+  T fx, fy;         // bilinear fractions (distance to the west / north tap)
+  T gmx, gmy;       // d ix / d xn (= W/2), zeroed by the zeros-mode overwrite or the border clip
+  int x0, y0;       // north-west tap
+  unsigned inb;     // bit k: tap k (0 nw, 1 ne, 2 sw, 3 se) lies inside the image
+  bool valid;       // max(|xn|, |yn|) <= 1   (inverse_warp.py:264)
+};
+
+template <typename T>
+__device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int u, int v, T depth,
+                                                   int H, int W, bool border) {
+  Sample<T> s;
+  const T uf = T(u), vf = T(v);
+  s.rx = bc.Kinv[0] * uf + bc.Kinv[1] * vf + bc.Kinv[2];
+  s.ry = bc.Kinv[3] * uf + bc.Kinv[4] * vf + bc.Kinv[5];
+  s.rz = bc.Kinv[6] * uf + bc.Kinv[7] * vf + bc.Kinv[8];
+  const T cx = s.rx * depth, cy = s.ry * depth, cz = s.rz * depth;
+  s.X = bc.A[0] * cx + bc.A[1] * cy + bc.A[2] * cz + bc.c[0];
+  s.Y = bc.A[3] * cx + bc.A[4] * cy + bc.A[5] * cz + bc.c[1];
+  s.Zraw = bc.A[6] * cx + bc.A[7] * cy + bc.A[8] * cz + bc.c[2];
+  s.Z = t_max(s.Zraw, T(kZMin));
+  T xn = T(2) * (s.X / s.Z) / T(W - 1) - T(1);
+  T yn = T(2) * (s.Y / s.Z) / T(H - 1) - T(1);
+  s.gmx = T(0.5) * T(W);
+  s.gmy = T(0.5) * T(H);
+  if (!border) {  // inverse_warp.py:219-224: out-of-range coordinates become the constant 2
+    if (xn > T(1) || xn < T(-1)) { xn = T(2); s.gmx = T(0); }
+    if (yn > T(1) || yn < T(-1)) { yn = T(2); s.gmy = T(0); }
+  }
+  s.valid = t_max(t_abs(xn), t_abs(yn)) <= T(1);
+  // grid_sampler_unnormalize, align_corners=False
+  T ix = ((xn + T(1)) * T(W) - T(1)) * T(0.5);
+  T iy = ((yn + T(1)) * T(H) - T(1)) * T(0.5);
+  if (border) {  // clip_coordinates_set_grad: zero gradient on and outside the bounds
+    if (!(ix > T(0))) { ix = T(0); s.gmx = T(0); } else if (!(ix < T(W - 1))) { ix = T(W - 1); s.gmx = T(0); }
+    if (!(iy > T(0))) { iy = T(0); s.gmy = T(0); } else if (!(iy < T(H - 1))) { iy = T(H - 1); s.gmy = T(0); }
+  } else {  // keep the float->int conversion defined for NaN / huge coordinates
+    if (!(ix >= T(-2) && ix <= T(W + 1))) ix = T(-2);
+    if (!(iy >= T(-2) && iy <= T(H + 1))) iy = T(-2);
+  }
+  const T fx0 = t_floor(ix), fy0 = t_floor(iy);
+  s.fx = ix - fx0;
+  s.fy = iy - fy0;
+  s.x0 = int(fx0);
+  s.y0 = int(fy0);
+  const bool xw = s.x0 >= 0 && s.x0 < W, xe = s.x0 + 1 >= 0 && s.x0 + 1 < W;
+  const bool yn_ = s.y0 >= 0 && s.y0 < H, ys = s.y0 + 1 >= 0 && s.y0 + 1 < H;
+  s.inb = (xw && yn_ ? 1u : 0u) | (xe && yn_ ? 2u : 0u) | (xw && ys ? 4u : 0u) | (xe && ys ? 8u : 0u);
+  return s;
+}
+
+// The four taps of one plane (out-of-image taps read as 0, which is also what the gradient of
+// grid_sampler_2d with respect to the coordinates assumes).
+template <typename T>
+__device__ __forceinline__ void load_taps(const T* __restrict__ plane, const Sample<T>& s, int W, T* v) {
+  const long base = (long)s.y0 * W + s.x0;
+  v[0] = (s.inb & 1u) ? plane[base] : T(0);
+  v[1] = (s.inb & 2u) ? plane[base + 1] : T(0);
+  v[2] = (s.inb & 4u) ? plane[base + W] : T(0);
+  v[3] = (s.inb & 8u) ? plane[base + W + 1] : T(0);
+}
+
+template <typename T>
+__device__ __forceinline__ T bilerp(const T* v, T fx, T fy) {
+  const T e = T(1) - fx, so = T(1) - fy;  // ATen CPU kernel: nw = s*e, ne = s*w, sw = n*e, se = n*w
+  return v[0] * (so * e) + v[1] * (so * fx) + v[2] * (fy * e) + v[3] * (fy * fx);
+}
+template <typename T>
+__device__ __forceinline__ T bilerp_dx(const T* v, T fx, T fy) { return (v[1] - v[0]) * (T(1) - fy) + (v[3] - v[2]) * fy; }
+template <typename T>
+__device__ __forceinline__ T bilerp_dy(const T* v, T fx, T fy) { return (v[2] - v[0]) * (T(1) - fx) + (v[3] - v[1]) * fx; }
+
+// Gradient of one pixel's sampling position back to the target depth and to A|c.
+//   gix, giy : dL/d(ix, iy) (un-normalised sampling coordinates)
+//   gZ       : dL/d(computed depth) arriving directly
+// Returns dL/d depth(p); adds this pixel's contribution to acc[0..8] = dL/dA, acc[9..11] = dL/dc.
+template <typename T>
+__device__ __forceinline__ T pixel_geometry_bwd(const BatchConsts<T>& bc, const Sample<T>& s, T depth,
+                                                T gix, T giy, T gZ, int H, int W, T* acc) {
+  // ix = ((xn+1) W - 1)/2, xn = 2 (X/Z)/(W-1) - 1   (inverse_warp.py:217-218)
+  const T gqx = gix * s.gmx * (T(2) / T(W - 1));
+  const T gqy = giy * s.gmy * (T(2) / T(H - 1));
+  const T iz = T(1) / s.Z;
+  const T dX = gqx * iz;
+  const T dY = gqy * iz;
+  // Z = clamp(Zraw, min=1e-3): gradient passes where Zraw >= 1e-3 (inverse_warp.py:211)
+  const T dZ = (s.Zraw >= T(kZMin)) ? (gZ - (gqx * s.X + gqy * s.Y) * iz * iz) : T(0);
+  const T cx = s.rx * depth, cy = s.ry * depth, cz = s.rz * depth;
+  acc[0] += dX * cx; acc[1] += dX * cy; acc[2] += dX * cz;
+  acc[3] += dY * cx; acc[4] += dY * cy; acc[5] += dY * cz;
+  acc[6] += dZ * cx; acc[7] += dZ * cy; acc[8] += dZ * cz;
+  acc[9] += dX; acc[10] += dY; acc[11] += dZ;
+  const T gcx = bc.A[0] * dX + bc.A[3] * dY + bc.A[6] * dZ;
+  const T gcy = bc.A[1] * dX + bc.A[4] * dY + bc.A[7] * dZ;
+  const T gcz = bc.A[2] * dX + bc.A[5] * dY + bc.A[8] * dZ;
+  return s.rx * gcx + s.ry * gcy + s.rz * gcz;
+}
+
+// Scatter dL/d(projected depth) of one pixel into the gradient of the sampled depth map
+// (grid_sampler_2d_backward on the input; only in-image taps receive anything).
+template <typename T>
+__device__ __forceinline__ void scatter_taps(T* __restrict__ gplane, const Sample<T>& s, int W, T g) {
+  if (g == T(0)) return;
+  const T e = T(1) - s.fx, so = T(1) - s.fy;
+  const long base = (long)s.y0 * W + s.x0;
+  if (s.inb & 1u) atomicAdd(gplane + base, g * (so * e));
+  if (s.inb & 2u) atomicAdd(gplane + base + 1, g * (so * s.fx));
+  if (s.inb & 4u) atomicAdd(gplane + base + W, g * (s.fy * e));
+  if (s.inb & 8u) atomicAdd(gplane + base + W + 1, g * (s.fy * s.fx));
+}
+
+}  // namespace scsfm

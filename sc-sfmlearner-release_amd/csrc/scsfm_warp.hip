@@ -1,0 +1,204 @@
+// inverse_warp2 as maps (inverse_warp.py:230-269) and pose_vec2mat (inverse_warp.py:139-154):
+// the un-fused entry points of the boundary.  The training hot path does not go through here --
+// it uses the fused pair kernels in scsfm_pair.hip -- but `inverse_warp2` / `pose_vec2mat` are
+// public names of the reference's operator API (test_pose.py:71, test_vo.py:76) and the maps are
+// what the map-level parity tests compare.
+#include "scsfm_geom.h"
+
+namespace scsfm {
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void warp_fwd_kernel(
+    int H, int W, bool border, const T* __restrict__ img, const T* __restrict__ depth,
+    const T* __restrict__ ref_depth, const BatchConsts<T>* __restrict__ consts, T* __restrict__ out_img,
+    T* __restrict__ out_valid, T* __restrict__ out_pdepth, T* __restrict__ out_cdepth) {
+  const int b = blockIdx.z;
+  const int u = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const int v = blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave;
+  if (u >= W || v >= H) return;
+  const BatchConsts<T> bc = consts[b];
+  const long plane = (long)H * W, p = (long)v * W + u;
+  const Sample<T> s = project_pixel(bc, u, v, depth[b * plane + p], H, W, border);
+  T t[4];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    load_taps(img + (b * 3 + c) * plane, s, W, t);
+    out_img[(b * 3 + c) * plane + p] = bilerp(t, s.fx, s.fy);
+  }
+  load_taps(ref_depth + b * plane, s, W, t);
+  out_pdepth[b * plane + p] = bilerp(t, s.fx, s.fy);
+  out_valid[b * plane + p] = s.valid ? T(1) : T(0);
+  out_cdepth[b * plane + p] = s.Z;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void warp_bwd_kernel(
+    int H, int W, bool border, const T* __restrict__ img, const T* __restrict__ depth,
+    const T* __restrict__ ref_depth, const BatchConsts<T>* __restrict__ consts, const T* __restrict__ g_img,
+    const T* __restrict__ g_pdepth, const T* __restrict__ g_cdepth, T* __restrict__ g_depth,
+    T* __restrict__ g_ref_depth, double* __restrict__ gP) {
+  __shared__ double red[12 * (kThreads / kWave)];
+  const int b = blockIdx.z;
+  const int u = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const int v = blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave;
+  const BatchConsts<T> bc = consts[b];
+  const long plane = (long)H * W, p = (long)v * W + u;
+  T acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = T(0);
+  if (u < W && v < H) {
+    const T d = depth[b * plane + p];
+    const Sample<T> s = project_pixel(bc, u, v, d, H, W, border);
+    T gix = T(0), giy = T(0), t[4];
+    if (g_img) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        load_taps(img + (b * 3 + c) * plane, s, W, t);
+        const T g = g_img[(b * 3 + c) * plane + p];
+        gix += g * bilerp_dx(t, s.fx, s.fy);
+        giy += g * bilerp_dy(t, s.fx, s.fy);
+      }
+    }
+    if (g_pdepth) {
+      load_taps(ref_depth + b * plane, s, W, t);
+      const T g = g_pdepth[b * plane + p];
+      gix += g * bilerp_dx(t, s.fx, s.fy);
+      giy += g * bilerp_dy(t, s.fx, s.fy);
+      scatter_taps(g_ref_depth + b * plane, s, W, g);
+    }
+    const T gZ = g_cdepth ? g_cdepth[b * plane + p] : T(0);
+    g_depth[b * plane + p] += pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
+  }
+  double accd[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) accd[i] = double(acc[i]);
+  block_sum<12>(accd, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) atomicAdd(gP + 12 * b + i, accd[i]);
+  }
+}
+
+// pose_vec2mat forward / backward, one thread per batch element.
+template <typename T>
+__global__ void pose_mat_fwd_kernel(int B, int mode, const T* __restrict__ vec, T* __restrict__ mat) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const T* p = vec + 6 * b;
+  T R[9];
+  if (mode == SCSFM_ROT_QUAT) quat_to_R(p[3], p[4], p[5], R); else euler_to_R(p[3], p[4], p[5], R);
+  T* m = mat + 12 * b;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    m[4 * r] = R[3 * r]; m[4 * r + 1] = R[3 * r + 1]; m[4 * r + 2] = R[3 * r + 2]; m[4 * r + 3] = p[r];
+  }
+}
+
+template <typename T>
+__global__ void pose_mat_bwd_kernel(int B, int mode, const T* __restrict__ vec, const T* __restrict__ g_mat,
+                                    T* __restrict__ g_vec) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const T* p = vec + 6 * b;
+  const T* g = g_mat + 12 * b;
+  T gR[9], ga[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { gR[3 * r] = g[4 * r]; gR[3 * r + 1] = g[4 * r + 1]; gR[3 * r + 2] = g[4 * r + 2]; }
+  if (mode == SCSFM_ROT_QUAT) quat_bwd(p[3], p[4], p[5], gR, ga); else euler_bwd(p[3], p[4], p[5], gR, ga);
+  T* o = g_vec + 6 * b;
+  o[0] = g[3]; o[1] = g[7]; o[2] = g[11];
+  o[3] = ga[0]; o[4] = ga[1]; o[5] = ga[2];
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side of the C ABI.
+// ------------------------------------------------------------------------------------------
+static inline size_t warp_ws_gP_offset(int B) { return (size_t)B * sizeof(BatchConsts<double>); }
+
+template <typename T>
+static int warp_fwd(int B, int H, int W, const T* img, const T* depth, const T* ref_depth, const T* pose,
+                    const T* K, unsigned flags, void* ws, T* o_img, T* o_valid, T* o_pd, T* o_cd, void* stream_) {
+  if (B <= 0 || H < 2 || W < 2 || !img || !depth || !ref_depth || !pose || !K || !ws || !o_img || !o_valid ||
+      !o_pd || !o_cd)
+    return SCSFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  auto* consts = reinterpret_cast<BatchConsts<T>*>(ws);
+  hipLaunchKernelGGL((prep_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, consts);
+  dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
+  hipLaunchKernelGGL((warp_fwd_kernel<T>), grid, dim3(kThreads), 0, stream, H, W, (flags & SCSFM_PAD_BORDER) != 0,
+                     img, depth, ref_depth, (const BatchConsts<T>*)consts, o_img, o_valid, o_pd, o_cd);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int warp_bwd(int B, int H, int W, const T* img, const T* depth, const T* ref_depth, const T* pose,
+                    const T* K, unsigned flags, void* ws, const T* g_img, const T* g_pd, const T* g_cd,
+                    T* g_depth, T* g_ref_depth, T* g_pose, void* stream_) {
+  if (B <= 0 || H < 2 || W < 2 || !img || !depth || !ref_depth || !pose || !K || !ws || !g_depth || !g_pose)
+    return SCSFM_ERR_ARG;
+  if (g_pd && !g_ref_depth) return SCSFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  auto* consts = reinterpret_cast<BatchConsts<T>*>(ws);
+  double* gP = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + warp_ws_gP_offset(B));
+  hipError_t e = hipMemsetAsync(gP, 0, (size_t)B * 12 * sizeof(double), stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((prep_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, consts);
+  dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
+  hipLaunchKernelGGL((warp_bwd_kernel<T>), grid, dim3(kThreads), 0, stream, H, W, (flags & SCSFM_PAD_BORDER) != 0,
+                     img, depth, ref_depth, (const BatchConsts<T>*)consts, g_img, g_pd, g_cd, g_depth, g_ref_depth,
+                     gP);
+  hipLaunchKernelGGL((pose_bwd_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K,
+                     (const double*)gP, g_pose);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int pose_fwd(int B, const T* vec, int mode, T* mat, void* stream) {
+  if (B <= 0 || !vec || !mat || (mode != SCSFM_ROT_EULER && mode != SCSFM_ROT_QUAT)) return SCSFM_ERR_ARG;
+  hipLaunchKernelGGL((pose_mat_fwd_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, B, mode, vec,
+                     mat);
+  return (int)hipGetLastError();
+}
+template <typename T>
+static int pose_bwd(int B, const T* vec, int mode, const T* g_mat, T* g_vec, void* stream) {
+  if (B <= 0 || !vec || !g_mat || !g_vec || (mode != SCSFM_ROT_EULER && mode != SCSFM_ROT_QUAT)) return SCSFM_ERR_ARG;
+  hipLaunchKernelGGL((pose_mat_bwd_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, B, mode, vec,
+                     g_mat, g_vec);
+  return (int)hipGetLastError();
+}
+
+}  // namespace scsfm
+
+extern "C" {
+
+int scsfm_abi_version(void) { return 1; }
+
+size_t scsfm_warp_ws_bytes(int B) {
+  if (B <= 0) return 0;
+  return (scsfm::warp_ws_gP_offset(B) + (size_t)B * 12 * sizeof(double) + 255) & ~(size_t)255;
+}
+
+#define SCSFM_WARP_API(SUF, T)                                                                                        \
+  int scsfm_warp_fwd_##SUF(int B, int H, int W, const T* img, const T* depth, const T* ref_depth, const T* pose,      \
+                           const T* K, unsigned flags, void* ws, T* o_img, T* o_valid, T* o_pd, T* o_cd,              \
+                           void* stream) {                                                                            \
+    return scsfm::warp_fwd<T>(B, H, W, img, depth, ref_depth, pose, K, flags, ws, o_img, o_valid, o_pd, o_cd,         \
+                              stream);                                                                                \
+  }                                                                                                                   \
+  int scsfm_warp_bwd_##SUF(int B, int H, int W, const T* img, const T* depth, const T* ref_depth, const T* pose,      \
+                           const T* K, unsigned flags, void* ws, const T* g_img, const T* g_pd, const T* g_cd,        \
+                           T* g_depth, T* g_ref_depth, T* g_pose, void* stream) {                                     \
+    return scsfm::warp_bwd<T>(B, H, W, img, depth, ref_depth, pose, K, flags, ws, g_img, g_pd, g_cd, g_depth,         \
+                              g_ref_depth, g_pose, stream);                                                           \
+  }                                                                                                                   \
+  int scsfm_pose_vec2mat_fwd_##SUF(int B, const T* vec, int mode, T* mat, void* stream) {                             \
+    return scsfm::pose_fwd<T>(B, vec, mode, mat, stream);                                                             \
+  }                                                                                                                   \
+  int scsfm_pose_vec2mat_bwd_##SUF(int B, const T* vec, int mode, const T* g_mat, T* g_vec, void* stream) {           \
+    return scsfm::pose_bwd<T>(B, vec, mode, g_mat, g_vec, stream);                                                    \
+  }
+
+SCSFM_WARP_API(f32, float)
+SCSFM_WARP_API(f64, double)
+
+}  // extern "C"

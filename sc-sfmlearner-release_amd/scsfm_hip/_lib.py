@@ -1,0 +1,87 @@
+"""ctypes binding of the C ABI declared in include/scsfm_hip.h.
+
+``get()`` returns the product library, libscsfm_hip.so (hipcc, gfx950), and nothing else: if the
+shared object is missing it is built in-tree with hipcc, and if that is impossible the call raises
+-- there is no CPU or eager fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "scsfm_hip.h")
+LIB_PATH = os.path.join(HERE, "libscsfm_hip.so")
+
+_CTYPES = {"int": ctypes.c_int, "unsigned": ctypes.c_uint, "size_t": ctypes.c_size_t}
+_DECL = re.compile(r"^(int|size_t)\s+(scsfm_\w+)\s*\(([^)]*)\)\s*;", re.M | re.S)
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every function the header declares."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for ret, name, args in _DECL.findall(text):
+        argtypes = []
+        args = " ".join(args.split())
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_CTYPES[a.split()[0]])
+        out[name] = (_CTYPES[ret], argtypes)
+    return out
+
+
+class ScsfmError(RuntimeError):
+    pass
+
+
+class CLib:
+    """A loaded implementation of the C ABI.  Every declared symbol must be present."""
+
+    def __init__(self, path):
+        self.path = path
+        self._dll = ctypes.CDLL(path)
+        self.decls = parse_header()
+        for name, (ret, argtypes) in self.decls.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError as e:
+                raise ScsfmError(f"{path} does not export {name} (declared in {HEADER})") from e
+            fn.restype = ret
+            fn.argtypes = argtypes
+        if self._dll.scsfm_abi_version() != 1:
+            raise ScsfmError(f"{path}: ABI version mismatch")
+
+    def call(self, name, *args):
+        """Invoke an int-returning entry point; raise on a non-zero status."""
+        rc = getattr(self._dll, name)(*args)
+        if rc != 0:
+            kind = "rejected argument" if rc == -1 else "hipError_t"
+            raise ScsfmError(f"{name} failed with status {rc} ({kind})")
+
+    def size(self, name, *args):
+        return int(getattr(self._dll, name)(*args))
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def get() -> CLib:
+    """The HIP library (singleton).  Builds it with hipcc on first use if it is not there."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    from . import build as _build
+                    _build.build()
+                _lib = CLib(LIB_PATH)
+    return _lib

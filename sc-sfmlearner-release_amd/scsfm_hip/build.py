@@ -1,0 +1,58 @@
+"""Build libscsfm_hip.so (gfx950) in-tree with hipcc.
+
+    python -m scsfm_hip.build        (from sc-sfmlearner-release_amd/)
+
+The shared object is plain HIP + a C ABI (include/scsfm_hip.h); it does not link against torch.
+It is written next to this file so that it travels with the source tree to the GPU box.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "csrc")
+LIB = os.path.join(HERE, "libscsfm_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-munsafe-fp-atomics",
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def deps():
+    return sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + \
+        [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "scsfm_hip.h")]
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in deps())
+
+
+def build(force=False, verbose=True, extra=()):
+    """Compile every .hip file under csrc/ into one shared object.  Raises on failure."""
+    if not force and not is_stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: libscsfm_hip.so cannot be built on this machine")
+    tmp = LIB + ".tmp"
+    cmd = [hipcc, *FLAGS, *extra, "-o", tmp, *sources()]
+    if verbose:
+        print("[scsfm_hip.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

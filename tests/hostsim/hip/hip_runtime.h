@@ -1,0 +1,217 @@
+// hostsim -- a tiny host-side stand-in for <hip/hip_runtime.h>.  TEST INFRASTRUCTURE ONLY.
+//
+// tests/hostsim/build.py compiles the product's kernel sources (sc-sfmlearner-release_amd/csrc)
+// UNCHANGED with g++ against this header, so that the CPU-only CI (`pytest -m "not gpu"`) can run
+// the kernels' tiling / halo / reduction / gradient logic against the oracle without a GPU.  It is
+// never shipped, never loaded by the product (scsfm_hip/_lib.py only ever opens libscsfm_hip.so,
+// which is built by hipcc for gfx950) and proves nothing about performance.
+//
+// Execution model: one OS thread.  Every HIP thread of a workgroup is a ucontext fiber; blocks run
+// one after another; __syncthreads() and the wave-level shuffles are cooperative barriers among
+// the fibers of the block / of the 64-lane wave.  Atomics are plain read-modify-writes.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __HOSTSIM__ 1
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct double2 { double x, y; };
+static inline float2 make_float2(float x, float y) { return {x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "hostsim"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+
+namespace hostsim {
+constexpr int kWave = 64;
+constexpr size_t kStack = 256 * 1024;
+
+struct Fiber {
+  ucontext_t ctx;
+  bool done = false;
+};
+
+struct State {
+  dim3 grid, block;
+  int nthreads = 0, cur = 0, live = 0;
+  std::vector<Fiber> fibers;
+  std::vector<char> stacks;
+  ucontext_t main_ctx;
+  const std::function<void()>* body = nullptr;
+  // block barrier
+  int arrived = 0;
+  uint64_t gen = 0;
+  // wave barriers + exchange buffers
+  std::vector<int> w_arrived, w_live;
+  std::vector<uint64_t> w_gen;
+  std::vector<uint64_t> xbuf;
+};
+inline State& S() { static State s; return s; }
+
+struct Idx { unsigned x, y, z; };
+inline Idx& tidx() { static Idx v; return v; }
+inline Idx& bidx() { static Idx v; return v; }
+inline Idx& bdim() { static Idx v; return v; }
+inline Idx& gdim() { static Idx v; return v; }
+
+inline void set_thread(int t) {
+  State& s = S();
+  s.cur = t;
+  tidx().x = t % s.block.x;
+  tidx().y = (t / s.block.x) % s.block.y;
+  tidx().z = t / (s.block.x * s.block.y);
+}
+inline void yield() {
+  State& s = S();
+  int me = s.cur;
+  swapcontext(&s.fibers[me].ctx, &s.main_ctx);
+}
+inline void trampoline() {
+  State& s = S();
+  (*s.body)();
+  s.fibers[s.cur].done = true;
+  swapcontext(&s.fibers[s.cur].ctx, &s.main_ctx);
+}
+inline void block_barrier() {
+  State& s = S();
+  uint64_t g = s.gen;
+  if (++s.arrived >= s.live) { s.arrived = 0; s.gen++; return; }
+  while (s.gen == g) yield();
+}
+inline void wave_barrier() {
+  State& s = S();
+  int w = s.cur / kWave;
+  uint64_t g = s.w_gen[w];
+  if (++s.w_arrived[w] >= s.w_live[w]) { s.w_arrived[w] = 0; s.w_gen[w]++; return; }
+  while (s.w_gen[w] == g) yield();
+}
+template <class T>
+inline T shfl(T v, int src_lane) {
+  static_assert(sizeof(T) <= 8, "shuffle payload");
+  State& s = S();
+  int w = s.cur / kWave, lane = s.cur % kWave;
+  uint64_t bits = 0;
+  memcpy(&bits, &v, sizeof(T));
+  s.xbuf[w * kWave + lane] = bits;
+  wave_barrier();
+  T r = v;
+  int nl = s.nthreads - w * kWave; if (nl > kWave) nl = kWave;
+  if (src_lane >= 0 && src_lane < nl) memcpy(&r, &s.xbuf[w * kWave + src_lane], sizeof(T));
+  wave_barrier();
+  return r;
+}
+
+inline void run_block(const std::function<void()>& body) {
+  State& s = S();
+  int n = s.nthreads;
+  s.body = &body;
+  s.live = n; s.arrived = 0;
+  int nw = (n + kWave - 1) / kWave;
+  s.w_arrived.assign(nw, 0); s.w_gen.assign(nw, 0); s.w_live.assign(nw, 0);
+  for (int t = 0; t < n; ++t) s.w_live[t / kWave]++;
+  s.xbuf.assign((size_t)nw * kWave, 0);
+  for (int t = 0; t < n; ++t) {
+    Fiber& f = s.fibers[t];
+    f.done = false;
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = s.stacks.data() + (size_t)t * kStack;
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = &s.main_ctx;
+    makecontext(&f.ctx, (void (*)())trampoline, 0);
+  }
+  int remaining = n;
+  long spins = 0;
+  while (remaining > 0) {
+    int progressed = 0;
+    for (int t = 0; t < n; ++t) {
+      Fiber& f = s.fibers[t];
+      if (f.done) continue;
+      set_thread(t);
+      swapcontext(&s.main_ctx, &f.ctx);
+      if (f.done) {
+        --remaining; ++progressed;
+        // a finished thread no longer takes part in barriers (hardware counts live waves only)
+        --s.live; --s.w_live[t / kWave];
+        if (s.live > 0 && s.arrived >= s.live) { s.arrived = 0; s.gen++; }
+        int w = t / kWave;
+        if (s.w_live[w] > 0 && s.w_arrived[w] >= s.w_live[w]) { s.w_arrived[w] = 0; s.w_gen[w]++; }
+      }
+    }
+    if (++spins > 100000000L) { fprintf(stderr, "hostsim: deadlock (divergent barrier?)\n"); abort(); }
+  }
+}
+
+inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+  State& s = S();
+  s.grid = grid; s.block = block;
+  s.nthreads = block.x * block.y * block.z;
+  if ((int)s.fibers.size() < s.nthreads) {
+    s.fibers.resize(s.nthreads);
+    s.stacks.resize((size_t)s.nthreads * kStack);
+  }
+  bdim() = {block.x, block.y, block.z};
+  gdim() = {grid.x, grid.y, grid.z};
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        bidx() = {bx, by, bz};
+        run_block(body);
+      }
+}
+}  // namespace hostsim
+
+#define threadIdx (hostsim::tidx())
+#define blockIdx (hostsim::bidx())
+#define blockDim (hostsim::bdim())
+#define gridDim (hostsim::gdim())
+#define warpSize 64
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                      \
+  do {                                                                                   \
+    (void)(shmem); (void)(stream);                                                       \
+    hostsim::launch(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); });            \
+  } while (0)
+
+static inline void __syncthreads() { hostsim::block_barrier(); }
+template <class T> static inline T __shfl_down(T v, unsigned d, int = 64) { return hostsim::shfl(v, hostsim::S().cur % 64 + (int)d); }
+template <class T> static inline T __shfl_up(T v, unsigned d, int = 64) { return hostsim::shfl(v, hostsim::S().cur % 64 - (int)d); }
+template <class T> static inline T __shfl_xor(T v, int m, int = 64) { return hostsim::shfl(v, (hostsim::S().cur % 64) ^ m); }
+template <class T> static inline T __shfl(T v, int l, int = 64) { return hostsim::shfl(v, l); }
+
+template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+static inline float atomicAdd(float* p, double v) { float o = *p; *p = o + (float)v; return o; }
+template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+static inline void __threadfence() {}
+
+// (__expf is declared by glibc itself)
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline float __saturatef(float x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
+static inline int __float2int_rd(float x) { return (int)floorf(x); }
+#define __builtin_amdgcn_readfirstlane(x) (x)
