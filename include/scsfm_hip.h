@@ -32,6 +32,8 @@ extern "C" {
 #define SCSFM_WITH_MASK 2u      /* loss_functions.py:111 */
 #define SCSFM_WITH_AUTO_MASK 4u /* loss_functions.py:103 */
 #define SCSFM_PAD_BORDER 8u     /* padding_mode == 'border' (default 'zeros'), inverse_warp.py:219-224,262 */
+#define SCSFM_LEGACY_GRID 16u   /* warp entry points only: no zeros-mode coordinate overwrite, as the
+                                   legacy inverse_warp / cam2pixel (inverse_warp.py:47-74,157-191) */
 
 #define SCSFM_ROT_EULER 0 /* inverse_warp.py:77-112  */
 #define SCSFM_ROT_QUAT 1  /* inverse_warp.py:115-136 */
@@ -49,9 +51,14 @@ int scsfm_abi_version(void);
  *
  * scsfm_pair_ws_bytes : size of the per-call device workspace `ws`.  The same `ws` must be handed,
  *                       untouched, from scsfm_pair_fwd to the matching scsfm_pair_bwd.
- * scsfm_pair_fwd      : out[4] (device, store) = { photo_loss, geometry_loss, sum(mask), 0 }.
- *                       The 10000-pixel gate of mean_on_mask is evaluated on the device: a gated-off
- *                       term is 0 and produces zero gradients (no host sync, unlike the reference).
+ * scsfm_pair_fwd      : out[8] (device, store) = { photo_loss, geometry_loss, S_photo, S_geom, S_mask,
+ *                       0, 0, 0 } with S_photo = sum_{c,p} diff_img*m, S_geom = sum_p diff_depth*m,
+ *                       S_mask = sum_p m.  The 10000-pixel gate of mean_on_mask is evaluated on the
+ *                       device: a gated-off term is 0 and produces zero gradients (no host sync,
+ *                       unlike the reference).
+ * scsfm_pair_refinalize : data-parallel exact mode -- after the caller has all-reduced out[2..4]
+ *                       over the ranks, recompute out[0..1] and the backward coefficients in `ws`
+ *                       from the global sums (the masked means are ratios of whole-batch sums).
  * scsfm_pair_bwd      : g_photo / g_geom are device scalars (upstream gradients of the two losses).
  *                       g_tgt_depth [B,1,H,W] accumulate (dense), g_ref_depth [B,1,H,W] accumulate
  *                       (atomic scatter of the bilinear taps), g_pose [B,6] store.
@@ -66,6 +73,8 @@ int scsfm_pair_bwd_f32(int B, int H, int W, const float* tgt_img, const float* r
                        const float* intrinsics, unsigned flags, void* ws, const float* g_photo,
                        const float* g_geom, float* g_tgt_depth, float* g_ref_depth, float* g_pose,
                        void* stream);
+int scsfm_pair_refinalize_f32(int B, int H, int W, void* ws, float* out, void* stream);
+int scsfm_pair_refinalize_f64(int B, int H, int W, void* ws, double* out, void* stream);
 int scsfm_pair_fwd_f64(int B, int H, int W, const double* tgt_img, const double* ref_img,
                        const double* tgt_depth, const double* ref_depth, const double* pose,
                        const double* intrinsics, unsigned flags, void* ws, double* out, void* stream);
@@ -80,7 +89,7 @@ int scsfm_pair_bwd_f64(int B, int H, int W, const double* tgt_img, const double*
  * (0/1), projected_depth [B,1,H,W], computed_depth [B,1,H,W] (all store).  The backward takes the
  * upstream gradients of the three differentiable maps (any may be NULL) and produces g_depth
  * (accumulate), g_ref_depth (accumulate, atomic scatter), g_pose [B,6] (store).  `ws` needs
- * scsfm_warp_ws_bytes(B) bytes.  Only SCSFM_PAD_BORDER is read from `flags`.
+ * scsfm_warp_ws_bytes(B) bytes.  Only SCSFM_PAD_BORDER and SCSFM_LEGACY_GRID are read from `flags`.
  * --------------------------------------------------------------------------------------------- */
 size_t scsfm_warp_ws_bytes(int B);
 
@@ -129,6 +138,33 @@ int scsfm_smooth_fwd_f64(int B, int H, int W, const double* depth, const double*
                          double* out, void* stream);
 int scsfm_smooth_bwd_f64(int B, int H, int W, const double* depth, const double* img, void* ws,
                          const double* g_loss, double* g_depth, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SSIM module (loss_functions.py:11-42) stand-alone: x, y [N,H,W] planes (N = B*C) ->
+ * out = clamp((1 - SSIM)/2, 0, 1) (store).  Backward: g_out -> g_x, g_y (store; either may be NULL).
+ * --------------------------------------------------------------------------------------------- */
+int scsfm_ssim_fwd_f32(int N, int H, int W, const float* x, const float* y, float* out, void* stream);
+int scsfm_ssim_bwd_f32(int N, int H, int W, const float* x, const float* y, const float* g_out,
+                       float* g_x, float* g_y, void* stream);
+int scsfm_ssim_fwd_f64(int N, int H, int W, const double* x, const double* y, double* out, void* stream);
+int scsfm_ssim_bwd_f64(int N, int H, int W, const double* x, const double* y, const double* g_out,
+                       double* g_x, double* g_y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * mean_on_mask (loss_functions.py:123-129): diff [B,C,HW], mask [B,Cm,HW] with Cm in {1, C}
+ * (broadcast over channels) -> out[1] = sum(diff*mask)/sum(mask) if sum(mask expanded) > 10000
+ * else 0 (store, gate on the device).  Backward: g (device scalar) -> g_diff [B,C,HW] (store).
+ * `ws` (scsfm_masked_mean_ws_bytes) carries the sums fwd -> bwd.
+ * --------------------------------------------------------------------------------------------- */
+size_t scsfm_masked_mean_ws_bytes(void);
+int scsfm_masked_mean_fwd_f32(int B, int C, int Cm, int HW, const float* diff, const float* mask,
+                              void* ws, float* out, void* stream);
+int scsfm_masked_mean_bwd_f32(int B, int C, int Cm, int HW, const float* mask, void* ws,
+                              const float* g, float* g_diff, void* stream);
+int scsfm_masked_mean_fwd_f64(int B, int C, int Cm, int HW, const double* diff, const double* mask,
+                              void* ws, double* out, void* stream);
+int scsfm_masked_mean_bwd_f64(int B, int C, int Cm, int HW, const double* mask, void* ws,
+                              const double* g, double* g_diff, void* stream);
 
 #ifdef __cplusplus
 }

@@ -137,7 +137,10 @@ struct Sample {
 
 template <typename T>
 __device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int u, int v, T depth,
-                                                   int H, int W, bool border) {
+                                                   int H, int W, unsigned flags) {
+  const bool border = (flags & SCSFM_PAD_BORDER) != 0;
+  // the legacy inverse_warp (inverse_warp.py:157-191 via cam2pixel :47-74) has no overwrite step
+  const bool overwrite = !border && (flags & SCSFM_LEGACY_GRID) == 0;
   Sample<T> s;
   const T uf = T(u), vf = T(v);
   s.rx = bc.Kinv[0] * uf + bc.Kinv[1] * vf + bc.Kinv[2];
@@ -152,7 +155,7 @@ __device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int
   T yn = T(2) * (s.Y / s.Z) / T(H - 1) - T(1);
   s.gmx = T(0.5) * T(W);
   s.gmy = T(0.5) * T(H);
-  if (!border) {  // inverse_warp.py:219-224: out-of-range coordinates become the constant 2
+  if (overwrite) {  // inverse_warp.py:219-224: out-of-range coordinates become the constant 2
     if (xn > T(1) || xn < T(-1)) { xn = T(2); s.gmx = T(0); }
     if (yn > T(1) || yn < T(-1)) { yn = T(2); s.gmy = T(0); }
   }

@@ -17,38 +17,9 @@
 // the target image of the tile + 1-pixel ring live in LDS; ring positions outside the image hold
 // the reflected pixel (ReflectionPad2d(1)).
 #include "scsfm_geom.h"
+#include "scsfm_ssim.h"
 
 namespace scsfm {
-
-template <typename T> struct Tile { static constexpr int kH = kTileH; };
-template <> struct Tile<double> { static constexpr int kH = 8; };  // keeps fp64 LDS under 64 KiB
-
-template <typename T>
-struct SsimStats {
-  T mux, muy, n1, n2, d1, d2, S, raw;
-};
-
-// Five 3x3 window sums -> SSIM terms (loss_functions.py:31-42).
-template <typename T>
-__device__ __forceinline__ SsimStats<T> ssim_stats(T sx, T sy, T sxx, T syy, T sxy) {
-  SsimStats<T> r;
-  const T k = T(1) / T(9);
-  r.mux = sx * k;
-  r.muy = sy * k;
-  const T sigx = sxx * k - r.mux * r.mux;
-  const T sigy = syy * k - r.muy * r.muy;
-  const T sigxy = sxy * k - r.mux * r.muy;
-  r.n1 = T(2) * r.mux * r.muy + T(kSsimC1);
-  r.n2 = T(2) * sigxy + T(kSsimC2);
-  r.d1 = r.mux * r.mux + r.muy * r.muy + T(kSsimC1);
-  r.d2 = sigx + sigy + T(kSsimC2);
-  r.S = (r.n1 * r.n2) / (r.d1 * r.d2);
-  r.raw = (T(1) - r.S) * T(0.5);
-  return r;
-}
-
-template <typename T>
-__device__ __forceinline__ T clamp01(T x) { return t_min(t_max(x, T(0)), T(1)); }
 
 // Warp one pixel (already reflected into the image): the three warped colours, the target
 // colours, and optionally everything else the loss needs at an owned pixel.
@@ -58,11 +29,11 @@ struct PixelOut {
 };
 
 template <typename T>
-__device__ __forceinline__ Sample<T> warp_colours(const BatchConsts<T>& bc, int u, int v, int H, int W, bool border,
+__device__ __forceinline__ Sample<T> warp_colours(const BatchConsts<T>& bc, int u, int v, int H, int W, unsigned flags,
                                                   const T* __restrict__ tgt_img, const T* __restrict__ ref_img,
                                                   const T* __restrict__ tgt_depth, PixelOut<T>& o) {
   const long plane = (long)H * W, p = (long)v * W + u;
-  const Sample<T> s = project_pixel(bc, u, v, tgt_depth[p], H, W, border);
+  const Sample<T> s = project_pixel(bc, u, v, tgt_depth[p], H, W, flags);
   T t[4];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -71,14 +42,6 @@ __device__ __forceinline__ Sample<T> warp_colours(const BatchConsts<T>& bc, int 
     o.It[c] = tgt_img[c * plane + p];
   }
   return s;
-}
-
-// Ring position r (0 .. 2*kHaloW + 2*TH - 1) -> (hy, hx) on the border of the (TH+2) x kHaloW tile.
-template <int TH>
-__device__ __forceinline__ void ring_pos(int r, int& hy, int& hx) {
-  if (r < kHaloW) { hy = 0; hx = r; }
-  else if (r < 2 * kHaloW) { hy = TH + 1; hx = r - kHaloW; }
-  else { r -= 2 * kHaloW; hy = 1 + (r >> 1); hx = (r & 1) ? kHaloW - 1 : 0; }
 }
 
 // ==========================================================================================
@@ -96,7 +59,7 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(
 
   const int b = blockIdx.z, col = threadIdx.x & (kWave - 1), strip = threadIdx.x / kWave;
   const int tx0 = blockIdx.x * kTileW, ty0 = blockIdx.y * TH;
-  const bool border = (flags & SCSFM_PAD_BORDER) != 0, with_mask = (flags & SCSFM_WITH_MASK) != 0,
+  const bool with_mask = (flags & SCSFM_WITH_MASK) != 0,
              with_auto = (flags & SCSFM_WITH_AUTO_MASK) != 0;
   const BatchConsts<T> bc = consts[b];
   const long plane = (long)H * W;
@@ -113,7 +76,7 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(
     const bool inimg = gx < W && gy < H;
     const int u = reflect_index(gx, W), v = reflect_index(gy, H);
     PixelOut<T> o;
-    const Sample<T> s = warp_colours(bc, u, v, H, W, border, tgt_img, ref_img, tgt_depth, o);
+    const Sample<T> s = warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, o);
     if (kSsim) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) { sIw[c][ly + 1][col + 1] = o.Iw[c]; sIt[c][ly + 1][col + 1] = o.It[c]; }
@@ -144,7 +107,7 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(
       ring_pos<TH>(threadIdx.x, hy, hx);
       const int u = reflect_index(tx0 + hx - 1, W), v = reflect_index(ty0 + hy - 1, H);
       PixelOut<T> o;
-      warp_colours(bc, u, v, H, W, border, tgt_img, ref_img, tgt_depth, o);
+      warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, o);
 #pragma unroll
       for (int c = 0; c < 3; ++c) { sIw[c][hy][hx] = o.Iw[c]; sIt[c][hy][hx] = o.It[c]; }
     }
@@ -197,6 +160,23 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(
   }
 }
 
+// The gates and divisions of mean_on_mask (loss_functions.py:123-129) on the three sums; also
+// publishes the coefficients the backward multiplies the upstream gradients with.
+// out[8] = {photo, geom, S_photo, S_geom, S_mask, 0, 0, 0}
+template <typename T>
+__device__ __forceinline__ void publish_losses(double Sp, double Sg, double Sm, double* __restrict__ sums,
+                                               T* __restrict__ out) {
+  // the photo mask is expanded over 3 channels before it is counted (loss_functions.py:124-125)
+  const bool gate_p = 3.0 * Sm > kMaskGate, gate_g = Sm > kMaskGate;
+  const double photo = gate_p ? Sp / (3.0 * Sm) : 0.0, geom = gate_g ? Sg / Sm : 0.0;
+  sums[0] = Sp; sums[1] = Sg; sums[2] = Sm; sums[3] = photo; sums[4] = geom;
+  sums[5] = gate_p ? 1.0 / (3.0 * Sm) : 0.0;  // d photo / d (diff_img_c * m)
+  sums[6] = gate_g ? 1.0 / Sm : 0.0;          // d geom  / d (diff_depth * m)
+  sums[7] = 0.0;
+  out[0] = T(photo); out[1] = T(geom); out[2] = T(Sp); out[3] = T(Sg); out[4] = T(Sm);
+  out[5] = T(0); out[6] = T(0); out[7] = T(0);
+}
+
 // One block: reduce the partials in fp64, apply the gates of mean_on_mask, publish the losses and
 // the coefficients the backward multiplies the upstream gradients with.
 template <typename T>
@@ -208,17 +188,15 @@ __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(int nblocks, co
     v[0] += partials[3 * i]; v[1] += partials[3 * i + 1]; v[2] += partials[3 * i + 2];
   }
   block_sum<3>(v, red);
-  if (threadIdx.x == 0) {
-    const double Sp = v[0], Sg = v[1], Sm = v[2];
-    // the photo mask is expanded over 3 channels before it is counted (loss_functions.py:124-125)
-    const bool gate_p = 3.0 * Sm > kMaskGate, gate_g = Sm > kMaskGate;
-    const double photo = gate_p ? Sp / (3.0 * Sm) : 0.0, geom = gate_g ? Sg / Sm : 0.0;
-    sums[0] = Sp; sums[1] = Sg; sums[2] = Sm; sums[3] = photo; sums[4] = geom;
-    sums[5] = gate_p ? 1.0 / (3.0 * Sm) : 0.0;  // d photo / d (diff_img_c * m)
-    sums[6] = gate_g ? 1.0 / Sm : 0.0;          // d geom  / d (diff_depth * m)
-    sums[7] = 0.0;
-    out[0] = T(photo); out[1] = T(geom); out[2] = T(Sm); out[3] = T(0);
-  }
+  if (threadIdx.x == 0) publish_losses(v[0], v[1], v[2], sums, out);
+}
+
+// Data-parallel "exact" mode: the caller all-reduces out[2..4] (the three raw sums)
+// over the ranks, then re-runs the gate / division on the global sums so that both the loss and the
+// backward coefficients are those of the concatenated batch.
+template <typename T>
+__global__ void pair_refinalize_kernel(double* __restrict__ sums, T* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) publish_losses(double(out[2]), double(out[3]), double(out[4]), sums, out);
 }
 
 // ==========================================================================================
@@ -244,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_kernel(
   const int b = blockIdx.z, col = threadIdx.x & (kWave - 1), strip = threadIdx.x / kWave;
   // the 64 x TH compute domain starts one pixel before the 62 x (TH-2) block of outputs
   const int ox = blockIdx.x * (kTileW - 2) - 1, oy = blockIdx.y * (TH - 2) - 1;
-  const bool border = (flags & SCSFM_PAD_BORDER) != 0, with_mask = (flags & SCSFM_WITH_MASK) != 0,
+  const bool with_mask = (flags & SCSFM_WITH_MASK) != 0,
              with_auto = (flags & SCSFM_WITH_AUTO_MASK) != 0;
   const BatchConsts<T> bc = consts[b];
   const long plane = (long)H * W;
@@ -268,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_kernel(
     inimg[k] = gx >= 0 && gx < W && gy >= 0 && gy < H;
     const int u = reflect_index(gx, W), v = reflect_index(gy, H);
     const long p = (long)v * W + u;
-    const Sample<T> s = project_pixel(bc, u, v, tgt_depth[p], H, W, border);
+    const Sample<T> s = project_pixel(bc, u, v, tgt_depth[p], H, W, flags);
     T t[4], Iw[3], It[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -308,7 +286,7 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_kernel(
       ring_pos<TH>(threadIdx.x, hy, hx);
       const int u = reflect_index(ox + hx - 1, W), v = reflect_index(oy + hy - 1, H);
       PixelOut<T> o;
-      warp_colours(bc, u, v, H, W, border, tgt_img, ref_img, tgt_depth, o);
+      warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, o);
 #pragma unroll
       for (int c = 0; c < 3; ++c) { sIw[c][hy][hx] = o.Iw[c]; sIt[c][hy][hx] = o.It[c]; }
     }
@@ -364,10 +342,10 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_kernel(
           T s1 = T(0), s2 = T(0), s3 = T(0);
 #pragma unroll
           for (int dy = -1; dy <= 1; ++dy) {
-            const T wy = (dy == -1 && py == 1) || (dy == 1 && py == H - 2) ? T(2) : T(1);
+            const T wy = reflect_mult<T>(dy, py, H);
 #pragma unroll
             for (int dx = -1; dx <= 1; ++dx) {
-              const T w = ((dx == -1 && px == 1) || (dx == 1 && px == W - 2) ? T(2) : T(1)) * wy;
+              const T w = reflect_mult<T>(dx, px, W) * wy;
               s1 += w * sG[0][ly + dy][col + dx];
               s2 += w * sG[1][ly + dy][col + dx];
               s3 += w * sG[2][ly + dy][col + dx];
@@ -401,7 +379,7 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_kernel(
     if (!mine) continue;  // note: m(p) = 0 still receives SSIM gradient through its neighbours' windows
     const long p = (long)py * W + px;
     const T d = tgt_depth[p];
-    const Sample<T> s = project_pixel(bc, px, py, d, H, W, border);
+    const Sample<T> s = project_pixel(bc, px, py, d, H, W, flags);
     T t[4];
     load_taps(ref_depth, s, W, t);
     const T Dp = bilerp(t, s.fx, s.fy);
@@ -486,6 +464,15 @@ static int pair_bwd(int B, int H, int W, const T* tgt_img, const T* ref_img, con
   return (int)hipGetLastError();
 }
 
+template <typename T>
+static int pair_refinalize(int B, int H, int W, void* ws, T* out, void* stream) {
+  if (B <= 0 || H < 2 || W < 2 || !ws || !out) return SCSFM_ERR_ARG;
+  const PairWs l = pair_ws_layout(B, H, W);
+  double* sums = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + l.off_sums);
+  hipLaunchKernelGGL((pair_refinalize_kernel<T>), dim3(1), dim3(kWave), 0, (hipStream_t)stream, sums, out);
+  return (int)hipGetLastError();
+}
+
 }  // namespace scsfm
 
 extern "C" {
@@ -511,6 +498,13 @@ size_t scsfm_pair_ws_bytes(int B, int H, int W) {
     return scsfm::pair_bwd<T>(B, H, W, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, ws, g_photo, g_geom,   \
                               g_tgt_depth, g_ref_depth, g_pose, stream);                                              \
   }
+
+int scsfm_pair_refinalize_f32(int B, int H, int W, void* ws, float* out, void* stream) {
+  return scsfm::pair_refinalize<float>(B, H, W, ws, out, stream);
+}
+int scsfm_pair_refinalize_f64(int B, int H, int W, void* ws, double* out, void* stream) {
+  return scsfm::pair_refinalize<double>(B, H, W, ws, out, stream);
+}
 
 SCSFM_PAIR_API(f32, float)
 SCSFM_PAIR_API(f64, double)

@@ -9,7 +9,7 @@ namespace scsfm {
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void warp_fwd_kernel(
-    int H, int W, bool border, const T* __restrict__ img, const T* __restrict__ depth,
+    int H, int W, unsigned flags, const T* __restrict__ img, const T* __restrict__ depth,
     const T* __restrict__ ref_depth, const BatchConsts<T>* __restrict__ consts, T* __restrict__ out_img,
     T* __restrict__ out_valid, T* __restrict__ out_pdepth, T* __restrict__ out_cdepth) {
   const int b = blockIdx.z;
@@ -18,7 +18,7 @@ __global__ __launch_bounds__(kThreads) void warp_fwd_kernel(
   if (u >= W || v >= H) return;
   const BatchConsts<T> bc = consts[b];
   const long plane = (long)H * W, p = (long)v * W + u;
-  const Sample<T> s = project_pixel(bc, u, v, depth[b * plane + p], H, W, border);
+  const Sample<T> s = project_pixel(bc, u, v, depth[b * plane + p], H, W, flags);
   T t[4];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kThreads) void warp_fwd_kernel(
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(
-    int H, int W, bool border, const T* __restrict__ img, const T* __restrict__ depth,
+    int H, int W, unsigned flags, const T* __restrict__ img, const T* __restrict__ depth,
     const T* __restrict__ ref_depth, const BatchConsts<T>* __restrict__ consts, const T* __restrict__ g_img,
     const T* __restrict__ g_pdepth, const T* __restrict__ g_cdepth, T* __restrict__ g_depth,
     T* __restrict__ g_ref_depth, double* __restrict__ gP) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(
   for (int i = 0; i < 12; ++i) acc[i] = T(0);
   if (u < W && v < H) {
     const T d = depth[b * plane + p];
-    const Sample<T> s = project_pixel(bc, u, v, d, H, W, border);
+    const Sample<T> s = project_pixel(bc, u, v, d, H, W, flags);
     T gix = T(0), giy = T(0), t[4];
     if (g_img) {
 #pragma unroll
@@ -125,7 +125,7 @@ static int warp_fwd(int B, int H, int W, const T* img, const T* depth, const T* 
   auto* consts = reinterpret_cast<BatchConsts<T>*>(ws);
   hipLaunchKernelGGL((prep_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, consts);
   dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
-  hipLaunchKernelGGL((warp_fwd_kernel<T>), grid, dim3(kThreads), 0, stream, H, W, (flags & SCSFM_PAD_BORDER) != 0,
+  hipLaunchKernelGGL((warp_fwd_kernel<T>), grid, dim3(kThreads), 0, stream, H, W, flags,
                      img, depth, ref_depth, (const BatchConsts<T>*)consts, o_img, o_valid, o_pd, o_cd);
   return (int)hipGetLastError();
 }
@@ -144,7 +144,7 @@ static int warp_bwd(int B, int H, int W, const T* img, const T* depth, const T* 
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL((prep_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, consts);
   dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
-  hipLaunchKernelGGL((warp_bwd_kernel<T>), grid, dim3(kThreads), 0, stream, H, W, (flags & SCSFM_PAD_BORDER) != 0,
+  hipLaunchKernelGGL((warp_bwd_kernel<T>), grid, dim3(kThreads), 0, stream, H, W, flags,
                      img, depth, ref_depth, (const BatchConsts<T>*)consts, g_img, g_pd, g_cd, g_depth, g_ref_depth,
                      gP);
   hipLaunchKernelGGL((pose_bwd_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K,

@@ -1,0 +1,118 @@
+"""Drop-in for the reference's ``loss_functions`` module, backed by hand-written HIP kernels.
+
+Same public names, positional signatures, return arity and flag conventions as
+/root/reference/loss_functions.py, so that ``from loss_functions import compute_smooth_loss,
+compute_photo_and_geometry_loss, compute_errors`` (train.py:19) resolves here when this directory
+precedes the reference on PYTHONPATH.
+
+What changes underneath: one ``compute_pairwise_loss`` is 182 ATen kernels forward
++ 221 backward in the reference; here it is one fused HIP kernel forward and one backward
+(csrc/scsfm_pair.hip).  ``compute_photo_and_geometry_loss`` puts all refs x scales x directions
+behind a single autograd node that accumulates the depth gradients in place.  The 10000-pixel gate
+of ``mean_on_mask`` is evaluated on the device, so the loss path never synchronises with the host;
+a gated-off term is a zero that still carries a (zero-gradient) ``grad_fn``, where the reference
+returns a fresh constant (loss_functions.py:128).
+
+All tensors must be HIP ('cuda') tensors.  There is no CPU path in this package.
+"""
+from __future__ import division
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from inverse_warp import inverse_warp, inverse_warp2  # noqa: F401  (re-exported like the reference, :5)
+from scsfm_hip import capi, ops
+
+device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+
+class SSIM(nn.Module):
+    """clamp((1 - SSIM(x, y)) / 2, 0, 1) over reflect-padded 3x3 windows (loss_functions.py:11-42).
+    Standalone HIP kernel (csrc/scsfm_aux.hip) with gradients to both inputs; inside the training
+    loss the same arithmetic runs fused in the pair kernels."""
+
+    def __init__(self):
+        super(SSIM, self).__init__()
+        self.C1 = 0.01 ** 2
+        self.C2 = 0.03 ** 2
+
+    def forward(self, x, y):
+        return ops.SsimMap.apply(x, y)
+
+
+compute_ssim_loss = SSIM().to(device)
+
+
+def compute_photo_and_geometry_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, poses, poses_inv,
+                                    max_scales, with_ssim, with_mask, with_auto_mask, padding_mode):
+    """loss_functions.py:50-92 -> (photo_loss, geometry_loss), summed over refs, scales and both
+    directions.  Scale s > 0 depth maps are nearest-upsampled to the image size (:81-82)."""
+    num_scales = min(len(tgt_depth), max_scales)
+    n_ref = len(ref_imgs)
+    if n_ref == 0 or num_scales <= 0:
+        return 0, 0  # the reference's accumulators stay the Python ints they start as (:52-53)
+    b, _, h, w = tgt_img.size()
+    flags = capi.make_flags(with_ssim, with_mask, with_auto_mask, padding_mode)
+
+    def full_res(d, s):
+        return d if s == 0 else F.interpolate(d, (h, w), mode='nearest')
+
+    tgt_full = [full_res(tgt_depth[s], s) for s in range(num_scales)]
+    ref_full = [full_res(ref_depths[i][s], s) for i in range(n_ref) for s in range(num_scales)]
+    return ops.PhotoGeometryLoss.apply(flags, n_ref, num_scales, tgt_img, intrinsics, *ref_imgs, *tgt_full, *ref_full,
+                                       *poses[:n_ref], *poses_inv[:n_ref])
+
+
+def compute_pairwise_loss(tgt_img, ref_img, tgt_depth, ref_depth, pose, intrinsic, with_ssim, with_mask,
+                          with_auto_mask, padding_mode):
+    """loss_functions.py:95-119 -> (reconstruction_loss, geometry_consistency_loss)."""
+    flags = capi.make_flags(with_ssim, with_mask, with_auto_mask, padding_mode)
+    return ops.PairwiseLoss.apply(flags, tgt_img, ref_img, tgt_depth, ref_depth, pose, intrinsic)
+
+
+def mean_on_mask(diff, valid_mask):
+    """sum(diff * mask) / sum(mask) if the expanded mask holds more than 10000 ones, else 0
+    (loss_functions.py:123-129); the gate is evaluated on the device."""
+    return ops.MaskedMean.apply(diff, valid_mask)
+
+
+def compute_smooth_loss(tgt_depth, tgt_img, ref_depths, ref_imgs):
+    """loss_functions.py:132-159: edge-aware smoothness of the mean-normalised depth at scale 0,
+    summed over the target and every reference frame."""
+    depths = [tgt_depth[0]] + [rd[0] for rd, _ in zip(ref_depths, ref_imgs)]
+    imgs = [tgt_img] + [im for _, im in zip(ref_depths, ref_imgs)]
+    return ops.SmoothLoss.apply(len(depths), *depths, *imgs)
+
+
+@torch.no_grad()
+def compute_errors(gt, pred, dataset):
+    """loss_functions.py:162-205 -> [abs_diff, abs_rel, sq_rel, a1, a2, a3] (Python floats, batch
+    means).  Validation-only; boolean-mask gathers and per-image medians stay on PyTorch device ops
+    (SURVEY.md §8 a11), the six metric sums are accumulated on the device and read back once."""
+    batch_size, h, w = gt.size()
+    if dataset == 'kitti':  # Garg/Eigen crop
+        y1, y2 = int(0.40810811 * h), int(0.99189189 * h)
+        x1, x2 = int(0.03594771 * w), int(0.96405229 * w)
+        max_depth = 80
+    elif dataset == 'nyu':
+        y1, y2 = int(0.09375 * h), int(0.98125 * h)
+        x1, x2 = int(0.0640625 * w), int(0.9390625 * w)
+        max_depth = 10
+    else:
+        # the reference leaves crop_mask unbound for any other name (:172-185)
+        raise UnboundLocalError("dataset must be 'kitti' or 'nyu', got {!r}".format(dataset))
+    crop_mask = torch.zeros(h, w, dtype=torch.bool, device=gt.device)
+    crop_mask[y1:y2, x1:x2] = True
+    totals = torch.zeros(6, dtype=torch.float32, device=gt.device)
+    for current_gt, current_pred in zip(gt, pred):
+        valid = (current_gt > 0.1) & (current_gt < max_depth) & crop_mask
+        valid_gt = current_gt[valid]
+        valid_pred = current_pred[valid].clamp(1e-3, max_depth)
+        valid_pred = valid_pred * torch.median(valid_gt) / torch.median(valid_pred)
+        thresh = torch.max(valid_gt / valid_pred, valid_pred / valid_gt)
+        err = torch.abs(valid_gt - valid_pred)
+        totals += torch.stack([err.mean(), (err / valid_gt).mean(), (err ** 2 / valid_gt).mean(),
+                               (thresh < 1.25).float().mean(), (thresh < 1.25 ** 2).float().mean(),
+                               (thresh < 1.25 ** 3).float().mean()]).float()
+    return [v / batch_size for v in totals.tolist()]

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-WITH_SSIM, WITH_MASK, WITH_AUTO_MASK, PAD_BORDER = 1, 2, 4, 8
+WITH_SSIM, WITH_MASK, WITH_AUTO_MASK, PAD_BORDER, LEGACY_GRID = 1, 2, 4, 8, 16
 ROT = {"euler": 0, "quat": 1}
 
 
@@ -47,6 +47,13 @@ def _chk(*ts):
             raise TypeError("all tensors of one call must share device and dtype")
         if not t.is_contiguous():
             raise ValueError("tensors must be contiguous")
+
+
+def check_sizes(t, name, expected):
+    """Shape guard with the reference's message (inverse_warp.py:20-26); raises AssertionError."""
+    ok = t.dim() == len(expected) and all(t.size(i) == e for i, e in enumerate(expected) if e is not None)
+    assert ok, "wrong size for {}, expected {}, got  {}".format(
+        name, "x".join("?" if e is None else str(e) for e in expected), list(t.size()))
 
 
 def _ws(lib, fn, like, *dims):
@@ -95,15 +102,34 @@ def pose_bwd(lib, vec, mode, g_mat):
 
 
 # -- compute_pairwise_loss ---------------------------------------------------------------------
-def pair_fwd(lib, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags):
-    """-> (out[4] = {photo, geom, sum_mask, 0}, ws).  ``ws`` must be handed to pair_bwd."""
-    _chk(tgt_img, ref_img, tgt_depth, ref_depth, pose, K)
+def pair_fwd_into(lib, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, out):
+    """Writes {photo, geom, S_photo, S_geom, S_mask, 0, 0, 0} into ``out`` (8 contiguous elements); returns the
+    workspace that must be handed to pair_bwd."""
+    _chk(tgt_img, ref_img, tgt_depth, ref_depth, pose, K, out)
     B, _, H, W = tgt_img.shape
+    check_sizes(ref_img, "ref_img", (B, 3, H, W))
+    check_sizes(tgt_depth, "tgt_depth", (B, 1, H, W))
+    check_sizes(ref_depth, "ref_depth", (B, 1, H, W))
+    check_sizes(pose, "pose", (B, 6))
+    check_sizes(K, "intrinsics", (B, 3, 3))
     ws = _ws(lib, "scsfm_pair_ws_bytes", tgt_img, B, H, W)
-    out = torch.empty(4, dtype=tgt_img.dtype, device=tgt_img.device)
     lib.call(f"scsfm_pair_fwd_{_suffix(tgt_img)}", B, H, W, _p(tgt_img), _p(ref_img), _p(tgt_depth), _p(ref_depth),
              _p(pose), _p(K), flags, _p(ws), _p(out), _stream(tgt_img))
+    return ws
+
+
+def pair_fwd(lib, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags):
+    """-> (out[8] = {photo, geom, S_photo, S_geom, S_mask, 0, 0, 0}, ws)."""
+    out = torch.empty(8, dtype=tgt_img.dtype, device=tgt_img.device)
+    ws = pair_fwd_into(lib, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, out)
     return out, ws
+
+
+def pair_refinalize(lib, shape, ws, out):
+    """Exact data-parallel mode: out[2..4] hold globally reduced sums; rewrites out[0..1] and the
+    backward coefficients inside ``ws``."""
+    B, H, W = shape
+    lib.call(f"scsfm_pair_refinalize_{_suffix(out)}", B, H, W, _p(ws), _p(out), _stream(out))
 
 
 def pair_bwd(lib, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, ws, g_photo, g_geom,
@@ -142,3 +168,110 @@ def smooth_bwd(lib, depth, img, ws, g_loss, g_depth=None):
     lib.call(f"scsfm_smooth_bwd_{_suffix(img)}", B, H, W, _p(depth), _p(img), _p(ws), _p(g_loss), _p(g_depth),
              _stream(img))
     return g_depth
+
+
+# -- SSIM layer / mean_on_mask (stand-alone public helpers) --------------------------------------
+def ssim_fwd(lib, x, y):
+    _chk(x, y)
+    assert x.shape == y.shape and x.dim() == 4, "SSIM expects two [B,C,H,W] tensors of equal shape"
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    lib.call(f"scsfm_ssim_fwd_{_suffix(x)}", B * C, H, W, _p(x), _p(y), _p(out), _stream(x))
+    return out
+
+
+def ssim_bwd(lib, x, y, g_out, need_x=True, need_y=True):
+    _chk(x, y, g_out)
+    B, C, H, W = x.shape
+    g_x = torch.empty_like(x) if need_x else None
+    g_y = torch.empty_like(y) if need_y else None
+    lib.call(f"scsfm_ssim_bwd_{_suffix(x)}", B * C, H, W, _p(x), _p(y), _p(g_out), _p(g_x), _p(g_y), _stream(x))
+    return g_x, g_y
+
+
+def masked_mean_fwd(lib, diff, mask):
+    _chk(diff, mask)
+    B, C = diff.shape[0], diff.shape[1]
+    HW = diff[0, 0].numel()
+    Cm = mask.shape[1]
+    assert mask.shape[0] == B and Cm in (1, C) and mask[0, 0].numel() == HW, "mask must broadcast over channels only"
+    ws = torch.empty(lib.size("scsfm_masked_mean_ws_bytes"), dtype=torch.uint8, device=diff.device)
+    out = torch.empty(1, dtype=diff.dtype, device=diff.device)
+    lib.call(f"scsfm_masked_mean_fwd_{_suffix(diff)}", B, C, Cm, HW, _p(diff), _p(mask), _p(ws), _p(out), _stream(diff))
+    return out, ws
+
+
+def masked_mean_bwd(lib, diff_shape, mask, ws, g):
+    _chk(mask, g)
+    B, C = diff_shape[0], diff_shape[1]
+    HW = 1
+    for d in diff_shape[2:]:
+        HW *= d
+    g_diff = torch.empty(diff_shape, dtype=mask.dtype, device=mask.device)
+    lib.call(f"scsfm_masked_mean_bwd_{_suffix(mask)}", B, C, mask.shape[1], HW, _p(mask), _p(ws), _p(g), _p(g_diff),
+             _stream(mask))
+    return g_diff
+
+
+# -- compute_photo_and_geometry_loss: refs x scales x both directions ----------------------------
+def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, group=None):
+    """All pair-directions of loss_functions.py:56-90.  ``tgt_depths[s]`` and
+    ``ref_depths[i][s]`` are full-resolution maps.  Returns (photo, geom, outs [n_pairs, 8], wss).
+
+    ``group``: a torch.distributed process group -> exact data-parallel mode: the three raw sums of
+    every pair are all-reduced (one [n_pairs, 3] collective) and the masked means are re-evaluated on
+    the global sums, so every rank holds the losses of the concatenated batch."""
+    n_ref, n_scales = len(ref_imgs), len(tgt_depths)
+    outs = torch.empty(2 * n_ref * n_scales, 8, dtype=tgt_img.dtype, device=tgt_img.device)
+    wss = []
+    j = 0
+    for i in range(n_ref):
+        for s in range(n_scales):
+            dt, dr = tgt_depths[s], ref_depths[i][s]
+            # direction tgt -> ref (loss_functions.py:84) then ref -> tgt (:86)
+            wss.append(pair_fwd_into(lib, tgt_img, ref_imgs[i], dt, dr, poses[i], K, flags, outs[j]))
+            wss.append(pair_fwd_into(lib, ref_imgs[i], tgt_img, dr, dt, poses_inv[i], K, flags, outs[j + 1]))
+            j += 2
+    if group is not None:
+        import torch.distributed as dist
+        sums = outs[:, 2:5].contiguous()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        outs[:, 2:5] = sums
+        B, _, H, W = tgt_img.shape
+        for j, ws in enumerate(wss):
+            pair_refinalize(lib, (B, H, W), ws, outs[j])
+    tot = outs[:, :2].sum(dim=0)  # plain sums over refs, scales and directions (loss_functions.py:89-90)
+    return tot[0], tot[1], outs, wss
+
+
+def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, wss, g_photo,
+                       g_geom):
+    """Gradients of photo_geometry_fwd's two sums: (g_tgt_depths[s], g_ref_depths[i][s], g_poses[i],
+    g_poses_inv[i]).  Each depth map's gradient buffer is zeroed once and then accumulated into by
+    every pair-direction that touches it (dense writes as target, atomic scatter as reference)."""
+    n_ref, n_scales = len(ref_imgs), len(tgt_depths)
+    g_td = [torch.zeros_like(t) for t in tgt_depths]
+    g_rd = [[torch.zeros_like(t) for t in r] for r in ref_depths]
+    g_poses, g_poses_inv = [], []
+    j = 0
+    for i in range(n_ref):
+        gp_i = gpi_i = None
+        for s in range(n_scales):
+            dt, dr = tgt_depths[s], ref_depths[i][s]
+            _, _, a = pair_bwd(lib, tgt_img, ref_imgs[i], dt, dr, poses[i], K, flags, wss[j], g_photo, g_geom,
+                               g_td[s], g_rd[i][s])
+            _, _, b = pair_bwd(lib, ref_imgs[i], tgt_img, dr, dt, poses_inv[i], K, flags, wss[j + 1], g_photo, g_geom,
+                               g_rd[i][s], g_td[s])
+            gp_i = a if gp_i is None else gp_i + a
+            gpi_i = b if gpi_i is None else gpi_i + b
+            j += 2
+        g_poses.append(gp_i)
+        g_poses_inv.append(gpi_i)
+    return g_td, g_rd, g_poses, g_poses_inv
+
+
+def smooth_multi_fwd(lib, depths, imgs):
+    """compute_smooth_loss (loss_functions.py:154-159): sum over frames -> (loss, wss)."""
+    outs = torch.empty(len(depths), dtype=imgs[0].dtype, device=imgs[0].device)
+    wss = [smooth_fwd(lib, d, im, outs[i:i + 1])[1] for i, (d, im) in enumerate(zip(depths, imgs))]
+    return outs.sum(), wss

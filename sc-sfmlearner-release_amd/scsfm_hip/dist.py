@@ -1,0 +1,82 @@
+"""Data-parallel helpers: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL on
+ROCm, over xGMI; "gloo" in the CPU tests).
+
+The loss path shards over the batch dimension with no collective in the default mode (each rank
+normalises its masked means by its own shard -- what any DDP port of the reference does; the
+reference itself runs the whole loss on GPU 0, train.py:168-169).  The optional *exact* mode
+reproduces the reference's whole-batch semantics (the masked means are ratios of global sums and
+the 10000-pixel gate is on the global count, loss_functions.py:123-129): one tiny all-reduce of
+the [n_pairs, 3] raw sums between the forward reduction and the backward kernels.  In that mode
+every rank returns the GLOBAL loss; multiply it by the world size before ``backward()`` if the
+parameter gradients are subsequently *averaged* (DistributedDataParallel) so that the averaged
+gradient equals the single-process gradient.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+_exact_group = None
+_exact_enabled = False
+
+
+def enable_exact_normalisation(group=None):
+    """Turn on the global-sum exchange for compute_photo_and_geometry_loss.  ``group=None`` means
+    the default (world) process group."""
+    import torch.distributed as dist
+    global _exact_group, _exact_enabled
+    if not dist.is_initialized():
+        raise RuntimeError("torch.distributed is not initialised")
+    _exact_group = group if group is not None else dist.group.WORLD
+    _exact_enabled = True
+
+
+def disable_exact_normalisation():
+    global _exact_group, _exact_enabled
+    _exact_group, _exact_enabled = None, False
+
+
+def exact_group():
+    return _exact_group if _exact_enabled else None
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment (1 process if absent)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_process_group_from_env(backend=None):
+    """Initialise torch.distributed for one-process-per-GPU runs launched by torchrun.  Backend
+    defaults to nccl (RCCL) when a GPU is visible, gloo otherwise.  Returns (rank, local_rank, world)."""
+    import torch.distributed as dist
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_batch(batch, rank, world):
+    """Slice every tensor of a synth.make_batch-style dict along dim 0 into this rank's shard
+    (global batch must be divisible by the world size)."""
+    def sl(t):
+        n = t.shape[0]
+        if n % world:
+            raise ValueError(f"global batch {n} is not divisible by world size {world}")
+        k = n // world
+        return t[rank * k:(rank + 1) * k].contiguous()
+
+    def rec(x):
+        if isinstance(x, torch.Tensor):
+            return sl(x)
+        if isinstance(x, (list, tuple)):
+            return [rec(y) for y in x]
+        return x
+
+    return {k: rec(v) for k, v in batch.items()}

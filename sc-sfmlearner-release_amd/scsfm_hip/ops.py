@@ -1,0 +1,235 @@
+"""torch.autograd.Function wrappers around the HIP kernels (through the C ABI, ``capi.py``).
+
+These are the product path: CUDA (HIP) tensors only, no eager / CPU fallback -- a missing
+libscsfm_hip.so or a CPU tensor raises.  Host-side there is no synchronisation: the reference's
+``if mask.sum() > 10000`` (loss_functions.py:125) is evaluated on the device.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, capi
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("scsfm_hip: tensors must live on a HIP device (torch 'cuda'); "
+                               "this package has no CPU fallback")
+
+
+def _no_grad_inputs(ctx, first, names):
+    for i, n in enumerate(names):
+        if ctx.needs_input_grad[first + i]:
+            raise NotImplementedError(f"scsfm_hip: gradient with respect to `{n}` is not provided "
+                                      "(the reference never asks for it: images and intrinsics are data)")
+
+
+def _c(t):
+    return t.contiguous()
+
+
+def _scalar(g, like):
+    if g is None:
+        return torch.zeros(1, dtype=like.dtype, device=like.device)
+    return g.reshape(1).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# compute_photo_and_geometry_loss: all refs x scales x both directions behind one autograd node
+# ------------------------------------------------------------------------------------------------
+class PhotoGeometryLoss(torch.autograd.Function):
+    """forward(flags, n_ref, n_scales, tgt_img, K, *ref_imgs, *tgt_depths, *ref_depths, *poses,
+    *poses_inv) -> (photo_loss, geometry_loss)
+
+    Depth maps are full resolution (scale s > 0 is nearest-upsampled by the caller, under
+    autograd).  ref_depths is flattened ref-major: ref_depths[i * n_scales + s].
+    Gradients: every depth map and every pose; images and K are data.
+    """
+
+    @staticmethod
+    def _split(rest, n_ref, n_scales):
+        o = 0
+        ref_imgs = list(rest[o:o + n_ref]); o += n_ref
+        tgt_depths = list(rest[o:o + n_scales]); o += n_scales
+        ref_depths = [list(rest[o + i * n_scales:o + (i + 1) * n_scales]) for i in range(n_ref)]; o += n_ref * n_scales
+        poses = list(rest[o:o + n_ref]); o += n_ref
+        poses_inv = list(rest[o:o + n_ref]); o += n_ref
+        return ref_imgs, tgt_depths, ref_depths, poses, poses_inv, o
+
+    @staticmethod
+    def forward(ctx, flags, n_ref, n_scales, tgt_img, K, *rest):
+        from . import dist as _dist
+        lib = _lib.get()
+        rest = [_c(t) for t in rest]
+        tgt_img, K = _c(tgt_img), _c(K)
+        _need_cuda(tgt_img, K, *rest)
+        ref_imgs, tgt_depths, ref_depths, poses, poses_inv, _ = PhotoGeometryLoss._split(rest, n_ref, n_scales)
+        photo, geom, _, wss = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
+                                                      poses_inv, group=_dist.exact_group())
+        ctx.flags, ctx.n_ref, ctx.n_scales = flags, n_ref, n_scales
+        ctx.save_for_backward(tgt_img, K, *rest, *wss)
+        return photo, geom
+
+    @staticmethod
+    def backward(ctx, g_photo, g_geom):
+        lib = _lib.get()
+        n_ref, n_scales, flags = ctx.n_ref, ctx.n_scales, ctx.flags
+        saved = ctx.saved_tensors
+        tgt_img, K = saved[0], saved[1]
+        _no_grad_inputs(ctx, 3, ["tgt_img", "intrinsics"] + [f"ref_imgs[{i}]" for i in range(n_ref)])
+        ref_imgs, tgt_depths, ref_depths, poses, poses_inv, n_in = PhotoGeometryLoss._split(saved[2:], n_ref, n_scales)
+        wss = saved[2 + n_in:]
+        g_td, g_rd, g_poses, g_poses_inv = capi.photo_geometry_bwd(
+            lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, wss,
+            _scalar(g_photo, tgt_img), _scalar(g_geom, tgt_img))
+        return (None, None, None, None, None, *([None] * n_ref), *g_td, *[g for r in g_rd for g in r], *g_poses,
+                *g_poses_inv)
+
+
+class PairwiseLoss(torch.autograd.Function):
+    """compute_pairwise_loss (loss_functions.py:95-119), one pair-direction -> (photo, geom)."""
+
+    @staticmethod
+    def forward(ctx, flags, tgt_img, ref_img, tgt_depth, ref_depth, pose, K):
+        lib = _lib.get()
+        args = [_c(t) for t in (tgt_img, ref_img, tgt_depth, ref_depth, pose, K)]
+        _need_cuda(*args)
+        out = torch.empty(8, dtype=args[0].dtype, device=args[0].device)
+        ws = capi.pair_fwd_into(lib, *args, flags, out)
+        ctx.flags = flags
+        ctx.save_for_backward(*args, ws)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_photo, g_geom):
+        lib = _lib.get()
+        tgt_img, ref_img, tgt_depth, ref_depth, pose, K, ws = ctx.saved_tensors
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or ctx.needs_input_grad[6]:
+            raise NotImplementedError("scsfm_hip: no gradient for images / intrinsics")
+        g_td, g_rd, g_pose = capi.pair_bwd(lib, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, ctx.flags, ws,
+                                           _scalar(g_photo, tgt_img), _scalar(g_geom, tgt_img))
+        return None, None, None, g_td, g_rd, g_pose, None
+
+
+# ------------------------------------------------------------------------------------------------
+# compute_smooth_loss: every frame behind one autograd node
+# ------------------------------------------------------------------------------------------------
+class SmoothLoss(torch.autograd.Function):
+    """forward(n, *depths, *imgs) -> sum_i get_smooth_loss(depths[i], imgs[i])
+    (loss_functions.py:132-159)."""
+
+    @staticmethod
+    def forward(ctx, n, *rest):
+        lib = _lib.get()
+        rest = [_c(t) for t in rest]
+        _need_cuda(*rest)
+        depths, imgs = rest[:n], rest[n:]
+        loss, wss = capi.smooth_multi_fwd(lib, depths, imgs)
+        ctx.n = n
+        ctx.save_for_backward(*rest, *wss)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.get()
+        n = ctx.n
+        saved = ctx.saved_tensors
+        depths, imgs, wss = saved[:n], saved[n:2 * n], saved[2 * n:]
+        if any(ctx.needs_input_grad[1 + n:]):
+            raise NotImplementedError("scsfm_hip: no gradient for images")
+        gl = _scalar(g, imgs[0])
+        grads = [capi.smooth_bwd(lib, d, im, ws, gl) if ctx.needs_input_grad[1 + i] else None
+                 for i, (d, im, ws) in enumerate(zip(depths, imgs, wss))]
+        return (None, *grads, *([None] * n))
+
+
+# ------------------------------------------------------------------------------------------------
+# inverse_warp2 as maps, pose_vec2mat
+# ------------------------------------------------------------------------------------------------
+class InverseWarp2(torch.autograd.Function):
+    """inverse_warp2 (inverse_warp.py:230-269) -> projected_img, valid_mask, projected_depth,
+    computed_depth."""
+
+    @staticmethod
+    def forward(ctx, flags, img, depth, ref_depth, pose, K):
+        lib = _lib.get()
+        args = [_c(t) for t in (img, depth, ref_depth, pose, K)]
+        _need_cuda(*args)
+        o_img, o_valid, o_pd, o_cd = capi.warp_fwd(lib, *args, flags)
+        ctx.flags = flags
+        ctx.save_for_backward(*args)
+        ctx.mark_non_differentiable(o_valid)
+        ctx.set_materialize_grads(False)  # unused maps arrive as None and are skipped by the kernel
+        return o_img, o_valid, o_pd, o_cd
+
+    @staticmethod
+    def backward(ctx, g_img, g_valid, g_pd, g_cd):
+        lib = _lib.get()
+        img, depth, ref_depth, pose, K = ctx.saved_tensors
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[5]:
+            raise NotImplementedError("scsfm_hip: no gradient for the sampled image / intrinsics")
+        cc = lambda t: None if t is None else t.contiguous()
+        g_depth, g_ref, g_pose = capi.warp_bwd(lib, img, depth, ref_depth, pose, K, ctx.flags, cc(g_img), cc(g_pd),
+                                               cc(g_cd))
+        return None, None, g_depth, g_ref, g_pose, None
+
+
+class PoseVec2Mat(torch.autograd.Function):
+    """pose_vec2mat (inverse_warp.py:139-154): [B,6] -> [B,3,4]."""
+
+    @staticmethod
+    def forward(ctx, vec, mode):
+        lib = _lib.get()
+        vec = _c(vec)
+        _need_cuda(vec)
+        ctx.mode = mode
+        ctx.save_for_backward(vec)
+        return capi.pose_fwd(lib, vec, mode)
+
+    @staticmethod
+    def backward(ctx, g_mat):
+        (vec,) = ctx.saved_tensors
+        return capi.pose_bwd(_lib.get(), vec, ctx.mode, g_mat.contiguous()), None
+
+
+# ------------------------------------------------------------------------------------------------
+# Stand-alone public helpers of the loss module
+# ------------------------------------------------------------------------------------------------
+class SsimMap(torch.autograd.Function):
+    """SSIM.forward (loss_functions.py:28-42) with gradients to both images."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _c(x), _c(y)
+        _need_cuda(x, y)
+        ctx.save_for_backward(x, y)
+        return capi.ssim_fwd(_lib.get(), x, y)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        nx, ny = ctx.needs_input_grad
+        if not (nx or ny):
+            return None, None
+        return capi.ssim_bwd(_lib.get(), x, y, g.contiguous(), nx, ny)
+
+
+class MaskedMean(torch.autograd.Function):
+    """mean_on_mask (loss_functions.py:123-129); the mask is treated as data."""
+
+    @staticmethod
+    def forward(ctx, diff, mask):
+        diff, mask = _c(diff), _c(mask)
+        _need_cuda(diff, mask)
+        out, ws = capi.masked_mean_fwd(_lib.get(), diff, mask)
+        ctx.shape = diff.shape
+        ctx.save_for_backward(mask, ws)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        mask, ws = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("scsfm_hip: mean_on_mask treats the mask as data (no gradient)")
+        return capi.masked_mean_bwd(_lib.get(), ctx.shape, mask, ws, _scalar(g, mask)), None

@@ -1,0 +1,276 @@
+"""CPU-only checks of the HIP kernels' logic: the product sources compiled unchanged against
+tests/hostsim (fibers instead of GPU threads) and compared with the oracle and the goldens recorded
+from the reference.  fp64 instantiations pin the formulas (1e-10); fp32 is what ships."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import assert_close_frac, leaf, load_inputs, load_npz
+from hostsim import harness
+from oracle import scsfm_oracle as O
+from scsfm_hip import capi, synth
+from scsfm_hip._lib import ScsfmError
+
+FLAGS = [(1, 1, 1), (1, 1, 0), (1, 0, 1), (1, 0, 0), (0, 1, 1), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return harness.lib()
+
+
+def _pair_inputs(d, dtype, pose_scale=1.0):
+    c = lambda x: x.to(dtype).contiguous()
+    return [c(d["tgt_img"]), c(d["ref_imgs"][0]), c(d["tgt_depth"][0]), c(d["ref_depths"][0][0]),
+            c(d["poses"][0] * pose_scale), c(d["intrinsics"])]
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-300))
+
+
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+@pytest.mark.parametrize("flags3", FLAGS)
+def test_pair_fp64_matches_oracle_autograd(lib, flags3, pad):
+    d = synth.make_batch(2, 72, 100, n_ref=1, seed=21, depth="smooth")  # ragged: partial tiles on both axes
+    ti, ri, td, rd, po, K = _pair_inputs(d, torch.float64)
+    ssim, mask, auto = flags3
+    fl = capi.make_flags(ssim, mask, auto, pad)
+    out, ws = capi.pair_fwd(lib, ti, ri, td, rd, po, K, fl)
+    tdl, rdl, pol = leaf(td), leaf(rd), leaf(po)
+    diff_img, diff_depth, m = O.pairwise_maps(ti, ri, tdl, rdl, pol, K, ssim, mask, auto, pad)
+    # compare the raw sums (independent of the 10000-pixel gate) ...
+    assert abs(float(out[4]) - float(m.sum())) == 0
+    assert abs(float(out[2]) - float((diff_img * m).sum().detach())) < 1e-9
+    assert abs(float(out[3]) - float((diff_depth * m).sum().detach())) < 1e-9
+    # ... and the gradients of the un-gated means
+    Sm = m.sum()
+    L = 0.7 * (diff_img * m).sum() / (3 * Sm) + 1.3 * (diff_depth * m).sum() / Sm
+    L.backward()
+    # open the gate for the kernel: scale the upstream gradients instead (linear)
+    gate_p = 1.0 if 3 * float(Sm) > 10000 else 0.0
+    gate_g = 1.0 if float(Sm) > 10000 else 0.0
+    assert gate_p == 1.0  # chosen sizes keep the photo gate open
+    gt, gr, gp = capi.pair_bwd(lib, ti, ri, td, rd, po, K, fl, ws, torch.tensor([0.7], dtype=torch.float64),
+                               torch.tensor([1.3], dtype=torch.float64))
+    if gate_g == 1.0:
+        assert _rel(gt, tdl.grad) < 1e-10 and _rel(gr, rdl.grad) < 1e-10 and _rel(gp, pol.grad) < 1e-10
+    else:  # geometry gated off: compare against the photo-only gradient
+        tdl2, rdl2, pol2 = leaf(td), leaf(rd), leaf(po)
+        di, dd, m2 = O.pairwise_maps(ti, ri, tdl2, rdl2, pol2, K, ssim, mask, auto, pad)
+        (0.7 * (di * m2).sum() / (3 * m2.sum())).backward()
+        assert _rel(gt, tdl2.grad) < 1e-10 and _rel(gp, pol2.grad) < 1e-10
+
+
+def test_pair_gate_closed_gives_zero_loss_and_zero_gradients(lib):
+    d = load_inputs("tiny")  # 2 x 24 x 40 = 1920 pixels: below both gates
+    ti, ri, td, rd, po, K = _pair_inputs(d, torch.float32)
+    fl = capi.make_flags(1, 1, 0, "zeros")
+    out, ws = capi.pair_fwd(lib, ti, ri, td, rd, po, K, fl)
+    assert float(out[0]) == 0.0 and float(out[1]) == 0.0 and float(out[4]) > 0
+    one = torch.ones(1)
+    gt, gr, gp = capi.pair_bwd(lib, ti, ri, td, rd, po, K, fl, ws, one, one)
+    assert float(gt.abs().max()) == 0 and float(gr.abs().max()) == 0 and float(gp.abs().max()) == 0
+    gold = load_npz("pair_tiny.npz")
+    assert float(gold["110_zeros/photo"]) == 0.0 and float(gold["110_zeros/geom"]) == 0.0
+
+
+@pytest.mark.parametrize("name", ["smooth", "iid"])
+def test_pair_fp32_matches_reference_goldens(lib, name):
+    d = load_inputs(name)
+    gold = load_npz(f"pair_{name}.npz")
+    ti, ri, td, rd, po, K = _pair_inputs(d, torch.float32)
+    w_photo, w_geom = torch.tensor([1.0]), torch.tensor([0.5])
+    for (ssim, mask, auto), pad in itertools.product(FLAGS, ("zeros", "border")):
+        key = f"{ssim}{mask}{auto}_{pad}"
+        fl = capi.make_flags(ssim, mask, auto, pad)
+        out, ws = capi.pair_fwd(lib, ti, ri, td, rd, po, K, fl)
+        # the parity bar of the path: 1e-5 absolute on the fp32 losses
+        assert abs(float(out[0]) - float(gold[f"{key}/photo"])) <= 1e-5, key
+        assert abs(float(out[1]) - float(gold[f"{key}/geom"])) <= 1e-5, key
+        gt, gr, gp = capi.pair_bwd(lib, ti, ri, td, rd, po, K, fl, ws, w_photo, w_geom)
+        g_pose = gold[f"{key}/g_pose"]
+        assert_close_frac(gp.numpy(), g_pose, atol=2e-3 * np.abs(g_pose).max() + 1e-7, what=key + " g_pose")
+        for nm, g in (("g_tgt_depth", gt), ("g_ref_depth", gr)):
+            st = gold[f"{key}/{nm}_stats"]
+            f = g.double().reshape(-1)
+            assert abs(float(f.abs().sum()) - st[1]) <= 2e-3 * st[1] + 1e-9, (key, nm)
+            if f"{key}/{nm}" in gold:
+                ref = gold[f"{key}/{nm}"]
+                # discontinuous gates may flip isolated pixels: bound their share
+                assert_close_frac(g.numpy(), ref, atol=2e-3 * np.abs(ref).max(), rtol=1e-3, max_bad_frac=2e-3,
+                                  what=f"{key} {nm}")
+
+
+@pytest.mark.parametrize("name", ["smooth", "iid"])
+def test_warp_maps_match_reference_goldens(lib, name):
+    d = load_inputs(name)
+    gold = load_npz(f"maps_{name}.npz")
+    ti, ri, td, rd, po, K = _pair_inputs(d, torch.float32)
+    for pad in ("zeros", "border"):
+        w, v, pd, cd = capi.warp_fwd(lib, ri, td, rd, po, K, capi.make_flags(padding_mode=pad))
+        assert (v.numpy().astype(np.uint8) != gold[f"{pad}/valid_mask"]).mean() <= 1e-3
+        # iid images have unit-scale differences between neighbours, so a 1e-4 px coordinate rounding
+        # difference shows up at the 1e-4 level in the sampled colours
+        assert_close_frac(w.numpy(), gold[f"{pad}/projected_img"], atol=3e-4, max_bad_frac=1e-3, what="img")
+        # same for the sampled depth (iid depth jumps by up to 100 between neighbours)
+        pd_atol = 1e-5 if name == "smooth" else 1e-4 * float(np.abs(gold[f"{pad}/projected_depth"]).max())
+        assert_close_frac(pd.numpy(), gold[f"{pad}/projected_depth"], atol=pd_atol, rtol=2e-5, max_bad_frac=1e-3,
+                          what="pdepth")
+        assert_close_frac(cd.numpy(), gold[f"{pad}/computed_depth"], atol=1e-5, rtol=1e-5, what="cdepth")
+
+
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_warp_backward_fp64(lib, pad):
+    d = synth.make_batch(2, 40, 72, n_ref=1, seed=5)
+    ti, ri, td, rd, po, K = _pair_inputs(d, torch.float64, pose_scale=3.0)
+    g = torch.Generator().manual_seed(1)
+    gi, gpd, gcd = (torch.randn(s, generator=g, dtype=torch.float64) for s in (ri.shape, td.shape, td.shape))
+    tdl, rdl, pol = leaf(td), leaf(rd), leaf(po)
+    ow, ov, opd, ocd = O.inverse_warp2(ri, tdl, rdl, pol, K, pad)
+    ((ow * gi).sum() + (opd * gpd).sum() + (ocd * gcd).sum()).backward()
+    gd, gr, gp = capi.warp_bwd(lib, ri, td, rd, po, K, capi.make_flags(padding_mode=pad), gi, gpd, gcd)
+    assert _rel(gd, tdl.grad) < 1e-10 and _rel(gr, rdl.grad) < 1e-10 and _rel(gp, pol.grad) < 1e-10
+    # missing upstream maps are skipped, not read
+    gd2, gr2, gp2 = capi.warp_bwd(lib, ri, td, rd, po, K, capi.make_flags(padding_mode=pad), gi, None, None)
+    tdl, rdl, pol = leaf(td), leaf(rd), leaf(po)
+    ow, _, _, _ = O.inverse_warp2(ri, tdl, rdl, pol, K, pad)
+    (ow * gi).sum().backward()
+    assert _rel(gd2, tdl.grad) < 1e-10 and float(gr2.abs().max()) == 0 and _rel(gp2, pol.grad) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["smooth", "iid"])
+def test_total_loss_fp32_matches_reference_goldens(lib, name):
+    """compute_photo_and_geometry_loss + compute_smooth_loss over 2 refs, 1 and 2 scales, through the
+    same capi pipeline the autograd node uses."""
+    d = load_inputs(name)
+    gold = load_npz(f"total_{name}.npz")
+    H, W = d["tgt_img"].shape[-2:]
+    for n_scales in (1, 2):
+        for ssim, mask, auto, pad in ((1, 1, 1, "zeros"), (1, 1, 0, "border")):
+            key = f"s{n_scales}_{ssim}{mask}{auto}_{pad}"
+            td = [leaf(x) for x in d["tgt_depth"]]
+            rd = [[leaf(x) for x in r] for r in d["ref_depths"]]
+            up = lambda t, s: t if s == 0 else F.interpolate(t, (H, W), mode="nearest")
+            td_full = [up(td[s], s) for s in range(n_scales)]
+            rd_full = [[up(r[s], s) for s in range(n_scales)] for r in rd]
+            det = lambda ts: [t.detach().contiguous() for t in ts]
+            fl = capi.make_flags(ssim, mask, auto, pad)
+            photo, geom, outs, wss = capi.photo_geometry_fwd(lib, fl, d["tgt_img"], d["intrinsics"], d["ref_imgs"],
+                                                             det(td_full), [det(r) for r in rd_full], d["poses"],
+                                                             d["poses_inv"])
+            smooth, sws = capi.smooth_multi_fwd(lib, [td[0].detach()] + [r[0].detach() for r in rd],
+                                                [d["tgt_img"]] + d["ref_imgs"])
+            assert abs(float(photo) - float(gold[f"{key}/photo"])) <= 1e-5
+            assert abs(float(geom) - float(gold[f"{key}/geom"])) <= 1e-5
+            assert abs(float(smooth) - float(gold[f"{key}/smooth"])) <= 1e-5
+            g_td, g_rd, g_p, g_pi = capi.photo_geometry_bwd(lib, fl, d["tgt_img"], d["intrinsics"], d["ref_imgs"],
+                                                            det(td_full), [det(r) for r in rd_full], d["poses"],
+                                                            d["poses_inv"], wss, torch.tensor([1.0]),
+                                                            torch.tensor([0.5]))
+            # chain through the nearest up-sampling (autograd, as loss_functions.py does) and add smooth
+            for s in range(n_scales):
+                td_full[s].backward(g_td[s]) if s > 0 else None
+                for i in range(2):
+                    rd_full[i][s].backward(g_rd[i][s]) if s > 0 else None
+            frames = [td[0]] + [r[0] for r in rd]
+            g_sm = [capi.smooth_bwd(lib, f.detach(), im, w, torch.tensor([0.1]))
+                    for f, im, w in zip(frames, [d["tgt_img"]] + d["ref_imgs"], sws)]
+            tot_t0 = g_td[0] + g_sm[0]
+            ref = gold[f"{key}/g_tgt_depth_s0"]
+            assert_close_frac(tot_t0.numpy(), ref, atol=2e-3 * np.abs(ref).max(), rtol=1e-3, max_bad_frac=2e-3,
+                              what=key + " tgt s0")
+            for i in range(2):
+                ref = gold[f"{key}/g_ref{i}_depth_s0"]
+                assert_close_frac((g_rd[i][0] + g_sm[1 + i]).numpy(), ref, atol=2e-3 * np.abs(ref).max(), rtol=1e-3,
+                                  max_bad_frac=2e-3, what=f"{key} ref{i} s0")
+                assert_close_frac(g_p[i].numpy(), gold[f"{key}/g_pose{i}"], atol=2e-3 * np.abs(gold[f"{key}/g_pose{i}"]).max())
+                assert_close_frac(g_pi[i].numpy(), gold[f"{key}/g_pose_inv{i}"],
+                                  atol=2e-3 * np.abs(gold[f"{key}/g_pose_inv{i}"]).max())
+            if n_scales == 2:
+                ref = gold[f"{key}/g_tgt_depth_s1"]
+                assert_close_frac(td[1].grad.numpy(), ref, atol=2e-3 * np.abs(ref).max(), rtol=1e-3, max_bad_frac=2e-3)
+
+
+def test_smooth_matches_oracle_and_golden(lib):
+    for dt, tol in ((torch.float64, 1e-12), (torch.float32, 2e-6)):
+        for B, H, W in ((2, 80, 112), (3, 37, 131), (1, 2, 2)):
+            d = synth.make_batch(B, H, W, n_ref=1, seed=5, depth="iid")
+            dep, img = d["tgt_depth"][0].to(dt), d["tgt_img"].to(dt)
+            out, ws = capi.smooth_fwd(lib, dep, img)
+            dl = leaf(dep)
+            L = O.smooth_term(dl, img)
+            (2.5 * L).backward()
+            g = capi.smooth_bwd(lib, dep, img, ws, torch.tensor([2.5], dtype=dt))
+            assert abs(float(out) - float(L)) <= tol * max(1.0, abs(float(L)))
+            assert _rel(g, dl.grad) <= (1e-10 if dt == torch.float64 else 1e-5)
+    d = load_inputs("smooth")
+    gold = load_npz("total_smooth.npz")
+    frames = [d["tgt_depth"][0]] + [r[0] for r in d["ref_depths"]]
+    imgs = [d["tgt_img"]] + d["ref_imgs"]
+    loss, wss = capi.smooth_multi_fwd(lib, frames, imgs)
+    assert abs(float(loss) - float(gold["smooth_only/loss"])) <= 1e-5
+    g0 = capi.smooth_bwd(lib, frames[0], imgs[0], wss[0], torch.ones(1))
+    assert_close_frac(g0.numpy(), gold["smooth_only/g_tgt_depth"], atol=1e-5 * np.abs(gold["smooth_only/g_tgt_depth"]).max(),
+                      rtol=1e-4)
+
+
+def test_pose_vec2mat_matches_golden(lib):
+    gold = load_npz("misc.npz")
+    vec = torch.from_numpy(gold["pose/vec"])
+    r = torch.from_numpy(gold["pose/probe"])
+    for mode in ("euler", "quat"):
+        M = capi.pose_fwd(lib, vec, mode)
+        np.testing.assert_allclose(M.numpy(), gold[f"pose/{mode}/mat"], atol=1e-6)
+        g = capi.pose_bwd(lib, vec, mode, r)
+        np.testing.assert_allclose(g.numpy(), gold[f"pose/{mode}/g_vec"], atol=3e-6)
+        v64 = vec.double()
+        vl = leaf(v64)
+        (O.pose_vec2mat(vl, mode) * r.double()).sum().backward()
+        assert _rel(capi.pose_bwd(lib, v64, mode, r.double()), vl.grad) < 1e-12
+
+
+def test_ssim_and_masked_mean_helpers(lib):
+    g = torch.Generator().manual_seed(0)
+    for dt, tol in ((torch.float64, 1e-11), (torch.float32, 3e-5)):
+        for shp in ((2, 3, 40, 72), (1, 1, 2, 2), (2, 2, 17, 130)):
+            x = torch.rand(shp, generator=g, dtype=dt)
+            y = (x + 0.3 * torch.rand(shp, generator=g, dtype=dt)).contiguous()
+            out = capi.ssim_fwd(lib, x, y)
+            xl, yl = leaf(x), leaf(y)
+            o = O.ssim_map(xl, yl)
+            go = torch.rand(shp, generator=g, dtype=dt)
+            (o * go).sum().backward()
+            gx, gy = capi.ssim_bwd(lib, x, y, go)
+            assert float((out - o).abs().max()) <= tol
+            assert _rel(gx, xl.grad) <= tol * 10 and _rel(gy, yl.grad) <= tol * 10
+        for shp, mshp in (((2, 3, 80, 112), (2, 1, 80, 112)), ((2, 3, 80, 112), (2, 3, 80, 112)),
+                          ((2, 1, 30, 40), (2, 1, 30, 40))):
+            diff = torch.rand(shp, generator=g, dtype=dt)
+            mask = (torch.rand(mshp, generator=g, dtype=dt) > 0.3).to(dt)
+            out, ws = capi.masked_mean_fwd(lib, diff, mask)
+            dl = leaf(diff)
+            o = O.mean_on_mask(dl, mask)
+            gd = capi.masked_mean_bwd(lib, shp, mask, ws, torch.tensor([1.7], dtype=dt))
+            assert abs(float(out) - float(o)) <= 1e-6
+            if o.requires_grad:
+                (1.7 * o).backward()
+                assert _rel(gd, dl.grad) <= 1e-6
+            else:
+                assert float(gd.abs().max()) == 0
+
+
+def test_rejected_arguments_raise(lib):
+    d = synth.make_batch(1, 8, 8, n_ref=1, seed=0)
+    ti, ri, td, rd, po, K = _pair_inputs(d, torch.float32)
+    with pytest.raises(AssertionError, match="wrong size for ref_depth"):
+        capi.pair_fwd(lib, ti, ri, td, rd[:, :, :4], po, K, 0)
+    with pytest.raises(ScsfmError, match="status -1"):
+        capi.smooth_fwd(lib, td[:, :, :1].contiguous(), ti[:, :, :1].contiguous())  # H = 1 < 2
+    with pytest.raises(TypeError):
+        capi.pair_fwd(lib, ti, ri, td.double(), rd, po, K, 0)
+    with pytest.raises(ValueError):
+        capi.make_flags(padding_mode="reflection")
