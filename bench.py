@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Benchmark of the SC-SfMLearner warp + loss hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch, exactly as train.py:262-268,280-281
+drives it: compute_photo_and_geometry_loss (2 refs x 2 directions) + compute_smooth_loss (3 frames),
+the weighted sum (1 / 0.1 / 0.5) and its backward down to the depth maps and poses.  Workload =
+BASELINE.json configs[1]: KITTI 256x832, batch 12 per GPU, sequence length 3, SSIM + mask + auto-mask,
+zeros padding, 1 scale; inputs are resident in HBM before the timed region.  Data-parallel runs
+shard by batch (weak scaling, 12 samples per GPU) with no collective on the loss path.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (pair_bwd_kernel): algorithmic bytes per launch (48 B/pixel x
+                  B*H*W) / its average launch duration measured here with HIP events on
+                  the launching stream, against the 8 TB/s HBM3E peak
+  cpu_baseline -- the CPU oracle (restatement of the reference's loss path on the same ATen CPU ops)
+                  timed on this host's cores on a bounded sample (cfg0: batch 4), rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "sc-sfmlearner-release_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy rate
+W_PHOTO, W_SMOOTH, W_GEOM = 1.0, 0.1, 0.5  # train.py:45-47 defaults used by scripts/train_resnet18_depth_256.sh
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def step_bytes(n_px, n_ref):
+    """Algorithmic (compulsory) HBM bytes of one step per GPU, BASELINE.md §2."""
+    return n_px * (48 * 2 * n_ref + 24 * (1 + n_ref))
+
+
+def make_inputs(args, seed, device):
+    from scsfm_hip import synth
+    d = synth.make_batch(args.batch, args.height, args.width, n_ref=args.n_ref, seed=seed, depth=args.depth,
+                         image="smooth" if args.depth == "smooth" else "iid", dataset=args.dataset)
+    to = lambda t: t.to(device)
+    return {
+        "tgt_img": to(d["tgt_img"]), "ref_imgs": [to(t) for t in d["ref_imgs"]], "K": to(d["intrinsics"]),
+        "tgt_depth": [to(t).requires_grad_(True) for t in d["tgt_depth"]],
+        "ref_depths": [[to(t).requires_grad_(True) for t in r] for r in d["ref_depths"]],
+        "poses": [to(t).requires_grad_(True) for t in d["poses"]],
+        "poses_inv": [to(t).requires_grad_(True) for t in d["poses_inv"]],
+    }, d
+
+
+def hot_path_step(LF, x, flags):
+    for t in x["tgt_depth"] + [t for r in x["ref_depths"] for t in r] + x["poses"] + x["poses_inv"]:
+        t.grad = None
+    photo, geom = LF.compute_photo_and_geometry_loss(x["tgt_img"], x["ref_imgs"], x["K"], x["tgt_depth"],
+                                                     x["ref_depths"], x["poses"], x["poses_inv"], 1, *flags)
+    smooth = LF.compute_smooth_loss(x["tgt_depth"], x["tgt_img"], x["ref_depths"], x["ref_imgs"])
+    loss = W_PHOTO * photo + W_SMOOTH * smooth + W_GEOM * geom
+    loss.backward()
+    return loss, photo, smooth, geom
+
+
+def time_kernels(x, flags, iters):
+    """Average launch duration (HIP events on the launching stream = torch's current stream) of the
+    pair forward and pair backward entry points, one pair-direction each."""
+    from scsfm_hip import _lib, capi
+    lib = _lib.get()
+    fl = capi.make_flags(*flags)
+    a = (x["tgt_img"], x["ref_imgs"][0], x["tgt_depth"][0].detach(), x["ref_depths"][0][0].detach(),
+         x["poses"][0].detach(), x["K"])
+    out, ws = capi.pair_fwd(lib, *a, fl)
+    one = torch.ones(1, device=a[0].device)
+    g_t, g_r = torch.zeros_like(a[2]), torch.zeros_like(a[3])
+    res = {}
+    for name, fn in (("pair_fwd", lambda: capi.pair_fwd_into(lib, *a, fl, out)),
+                     ("pair_bwd", lambda: capi.pair_bwd(lib, *a, fl, ws, one, one, g_t, g_r))):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / iters * 1e-3  # seconds per launch
+    dep, img = x["tgt_depth"][0].detach(), x["tgt_img"]
+    so, sws = capi.smooth_fwd(lib, dep, img)
+    for name, fn in (("smooth_fwd", lambda: capi.smooth_fwd(lib, dep, img, so)),
+                     ("smooth_bwd", lambda: capi.smooth_bwd(lib, dep, img, sws, one, g_t))):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / iters * 1e-3
+    return res
+
+
+def cpu_baseline(args, flags, budget_s):
+    """The oracle (ATen-CPU restatement of the reference loss path) forward + backward on host
+    cores, bounded to ~budget_s seconds; same generator, cfg0 batch size."""
+    from oracle import scsfm_oracle as O
+    from scsfm_hip import synth
+    B = min(4, args.batch)
+    d = synth.make_batch(B, args.height, args.width, n_ref=args.n_ref, seed=0, depth=args.depth,
+                         image="smooth" if args.depth == "smooth" else "iid", dataset=args.dataset)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one():
+        lf = lambda t: t.clone().requires_grad_(True)
+        td = [lf(t) for t in d["tgt_depth"]]
+        rd = [[lf(t) for t in r] for r in d["ref_depths"]]
+        ps, pi = [lf(p) for p in d["poses"]], [lf(p) for p in d["poses_inv"]]
+        photo, geom = O.photo_and_geometry_loss(d["tgt_img"], d["ref_imgs"], d["intrinsics"], td, rd, ps, pi, 1,
+                                                *flags, impl="aten")
+        smooth = O.smooth_loss(td, d["tgt_img"], rd, d["ref_imgs"])
+        (W_PHOTO * photo + W_SMOOTH * smooth + W_GEOM * geom).backward()
+
+    one()  # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end or len(times) < 3:
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (ATen CPU ops of the reference path) fwd+bwd, batch {B} x {args.height}x{args.width}, "
+                      f"{args.n_ref} refs, median of {len(times)} steps ({med * 1e3:.1f} ms/step)",
+            "ms_per_step": round(med * 1e3, 2),
+            "algorithmic_GBs": round(step_bytes(B * args.height * args.width, args.n_ref) / med / 1e9, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=12, help="samples per GPU (configs[1]: 12)")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=832)
+    ap.add_argument("--n-ref", type=int, default=2, help="sequence length - 1")
+    ap.add_argument("--dataset", default="kitti", choices=["kitti", "nyu"])
+    ap.add_argument("--depth", default="smooth", choices=["smooth", "iid"],
+                    help="synthetic depth law: smooth = realistic locality (headline), iid = incoherent gathers")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--kernel-iters", type=int, default=30)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device: the loss path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+
+    import loss_functions as LF
+    from scsfm_hip import _lib
+    lib = _lib.get()
+    assert lib.path.endswith("libscsfm_hip.so")
+
+    flags = (1, 1, 1, "zeros")  # with_ssim, with_mask, with_auto_mask, padding_mode (scripts/train_resnet18_depth_256.sh)
+    x, _ = make_inputs(args, seed=rank, device=device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = hot_path_step(LF, x, flags)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = hot_path_step(LF, x, flags)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss, photo, smooth, geom = (float(v) for v in out)
+
+    n_px = args.batch * args.height * args.width
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.batch * args.steps / elapsed
+
+    kt = time_kernels(x, flags, args.kernel_iters)
+    bwd_bytes = 48 * n_px  # one pair-direction backward launch: read 32 B/px, RMW 16 B/px
+    achieved = bwd_bytes / kt["pair_bwd"] / 1e9
+    roofline = {"bound": "hbm", "kernel": "pair_bwd_kernel<float,true>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_us": round(kt["pair_bwd"] * 1e6, 2)}
+    # sum of the kernel launches of one step, from the per-entry-point event timings
+    kernel_sum = args.n_ref * 2 * (kt["pair_fwd"] + kt["pair_bwd"]) + (1 + args.n_ref) * (kt["smooth_fwd"] + kt["smooth_bwd"])
+
+    if rank == 0:
+        res = {
+            "metric": "train images/sec through the warp+loss hot path (photo+geometry+smooth, fwd+bwd), "
+                      "KITTI 256x832 seq3",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {args.dataset} {args.height}x{args.width}, batch {args.batch}/GPU, "
+                                   f"{args.n_ref} refs (seq {args.n_ref + 1}), ssim+mask+auto-mask, zeros padding, "
+                                   f"1 scale, {args.depth} synthetic depth",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world} (batch shards, no loss-path collective)"},
+            "warp_loss_ms_per_step": round(ms_per_step, 4),
+            "step_algorithmic_GBs": round(step_bytes(n_px, args.n_ref) / (elapsed / args.steps) / 1e9, 1),
+            "step_frac_of_hbm_peak": round(step_bytes(n_px, args.n_ref) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernel_us": {k: round(v * 1e6, 2) for k, v in kt.items()},
+            "kernel_sum_ms_per_step": round(kernel_sum * 1e3, 4),
+            "losses": {"total": loss, "photo": photo, "smooth": smooth, "geometry": geom},
+            "roofline": roofline,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            res["cpu_baseline"] = cpu_baseline(args, flags, args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

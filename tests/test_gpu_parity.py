@@ -1,0 +1,289 @@
+"""GPU parity tests proper (run with `pytest -m gpu` on an MI355X): the product path -- the drop-in
+``loss_functions`` / ``inverse_warp`` modules -> autograd nodes -> ctypes -> libscsfm_hip.so -- against
+(1) the golden fixtures recorded from the unmodified reference, (2) the CPU oracle on seeded inputs,
+including BASELINE.json's full size, and (3) size-independent properties at full size.
+
+Tolerances (fp32): losses 1e-5 absolute (north_star); gradients compared entry-wise at 0.2 % of the
+tensor's scale with a small share of outliers allowed, because the path's gates (valid / auto mask,
+clamps) are discontinuous and a 1-ulp coordinate difference flips isolated pixels.
+"""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from _util import assert_close_frac, load_inputs, load_npz
+
+pytestmark = pytest.mark.gpu
+
+FLAGS = [(1, 1, 1), (1, 1, 0), (1, 0, 1), (1, 0, 0), (0, 1, 1), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from scsfm_hip import _lib
+    lib = _lib.get()
+    assert lib.path.endswith("libscsfm_hip.so")  # the hipcc build, not the simulator
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def LF(dev):
+    import loss_functions
+    return loss_functions
+
+
+@pytest.fixture(scope="module")
+def IW(dev):
+    import inverse_warp
+    return inverse_warp
+
+
+def _leaf(t, dev):
+    return t.to(dev).clone().requires_grad_(True)
+
+
+def _scale_close(a, b, rel=2e-3, bad=2e-3, what=""):
+    b = np.asarray(b)
+    assert_close_frac(a.detach().cpu().numpy(), b, atol=rel * float(np.abs(b).max()) + 1e-12, rtol=1e-3,
+                      max_bad_frac=bad, what=what)
+
+
+# ------------------------------------------------------------------------------------------------
+# 1. golden fixtures of the reference
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["smooth", "iid", "tiny"])
+def test_pairwise_loss_goldens(LF, dev, name):
+    d = load_inputs(name)
+    gold = load_npz(f"pair_{name}.npz")
+    tgt, ref, K = d["tgt_img"].to(dev), d["ref_imgs"][0].to(dev), d["intrinsics"].to(dev)
+    for (ssim, mask, auto), pad in itertools.product(FLAGS, ("zeros", "border")):
+        key = f"{ssim}{mask}{auto}_{pad}"
+        td, rd, po = _leaf(d["tgt_depth"][0], dev), _leaf(d["ref_depths"][0][0], dev), _leaf(d["poses"][0], dev)
+        photo, geom = LF.compute_pairwise_loss(tgt, ref, td, rd, po, K, ssim, mask, auto, pad)
+        assert abs(float(photo) - float(gold[f"{key}/photo"])) <= 1e-5, key
+        assert abs(float(geom) - float(gold[f"{key}/geom"])) <= 1e-5, key
+        (1.0 * photo + 0.5 * geom).backward()
+        _scale_close(po.grad, gold[f"{key}/g_pose"], what=key + " g_pose", bad=0.0) if name != "tiny" else None
+        for nm, t in (("g_tgt_depth", td), ("g_ref_depth", rd)):
+            st = gold[f"{key}/{nm}_stats"]
+            assert abs(float(t.grad.double().abs().sum()) - st[1]) <= 2e-3 * st[1] + 1e-9, (key, nm)
+            if f"{key}/{nm}" in gold:
+                _scale_close(t.grad, gold[f"{key}/{nm}"], what=f"{key} {nm}")
+
+
+@pytest.mark.parametrize("name", ["smooth", "iid"])
+def test_total_loss_goldens(LF, dev, name):
+    d = load_inputs(name)
+    gold = load_npz(f"total_{name}.npz")
+    tgt, refs, K = d["tgt_img"].to(dev), [r.to(dev) for r in d["ref_imgs"]], d["intrinsics"].to(dev)
+    for n_scales in (1, 2):
+        for ssim, mask, auto, pad in ((1, 1, 1, "zeros"), (1, 1, 0, "border")):
+            key = f"s{n_scales}_{ssim}{mask}{auto}_{pad}"
+            td = [_leaf(x, dev) for x in d["tgt_depth"]]
+            rd = [[_leaf(x, dev) for x in r] for r in d["ref_depths"]]
+            ps, pi = [_leaf(p, dev) for p in d["poses"]], [_leaf(p, dev) for p in d["poses_inv"]]
+            photo, geom = LF.compute_photo_and_geometry_loss(tgt, refs, K, td, rd, ps, pi, n_scales, ssim, mask, auto, pad)
+            smooth = LF.compute_smooth_loss(td, tgt, rd, refs)
+            for nm, v in (("photo", photo), ("geom", geom), ("smooth", smooth)):
+                assert abs(float(v) - float(gold[f"{key}/{nm}"])) <= 1e-5, (key, nm)
+            (1.0 * photo + 0.1 * smooth + 0.5 * geom).backward()
+            for s in range(n_scales):
+                _scale_close(td[s].grad, gold[f"{key}/g_tgt_depth_s{s}"], what=f"{key} tgt s{s}")
+                for i in range(2):
+                    _scale_close(rd[i][s].grad, gold[f"{key}/g_ref{i}_depth_s{s}"], what=f"{key} ref{i} s{s}")
+            for i in range(2):
+                _scale_close(ps[i].grad, gold[f"{key}/g_pose{i}"], bad=0.0)
+                _scale_close(pi[i].grad, gold[f"{key}/g_pose_inv{i}"], bad=0.0)
+
+
+@pytest.mark.parametrize("name", ["smooth", "iid"])
+def test_inverse_warp2_goldens(IW, dev, name):
+    d = load_inputs(name)
+    gold = load_npz(f"maps_{name}.npz")
+    for pad in ("zeros", "border"):
+        w, v, pd, cd = IW.inverse_warp2(d["ref_imgs"][0].to(dev), d["tgt_depth"][0].to(dev),
+                                        d["ref_depths"][0][0].to(dev), d["poses"][0].to(dev),
+                                        d["intrinsics"].to(dev), pad)
+        assert (v.cpu().numpy().astype(np.uint8) != gold[f"{pad}/valid_mask"]).mean() <= 1e-3
+        assert_close_frac(w.cpu().numpy(), gold[f"{pad}/projected_img"], atol=3e-4, max_bad_frac=1e-3)
+        pd_atol = 1e-5 if name == "smooth" else 1e-4 * float(np.abs(gold[f"{pad}/projected_depth"]).max())
+        assert_close_frac(pd.cpu().numpy(), gold[f"{pad}/projected_depth"], atol=pd_atol, rtol=2e-5, max_bad_frac=1e-3)
+        assert_close_frac(cd.cpu().numpy(), gold[f"{pad}/computed_depth"], atol=1e-5, rtol=1e-5)
+
+
+def test_pose_and_errors_goldens(LF, IW, dev):
+    gold = load_npz("misc.npz")
+    r = torch.from_numpy(gold["pose/probe"]).to(dev)
+    for mode in ("euler", "quat"):
+        v = _leaf(torch.from_numpy(gold["pose/vec"]), dev)
+        M = IW.pose_vec2mat(v, mode)
+        (M * r).sum().backward()
+        np.testing.assert_allclose(M.detach().cpu().numpy(), gold[f"pose/{mode}/mat"], atol=1e-6)
+        np.testing.assert_allclose(v.grad.cpu().numpy(), gold[f"pose/{mode}/g_vec"], atol=3e-6)
+    for ds in ("kitti", "nyu"):
+        out = LF.compute_errors(torch.from_numpy(gold[f"errors/{ds}/gt"]).to(dev),
+                                torch.from_numpy(gold[f"errors/{ds}/pred"]).to(dev), ds)
+        np.testing.assert_allclose(out, gold[f"errors/{ds}/out"], rtol=1e-5, atol=1e-6)  # AbsRel is out[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# 2. the CPU oracle on seeded inputs, up to BASELINE.json's full size
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,n_ref,dataset,depth", [
+    (2, 128, 416, 2, "kitti", "smooth"),
+    (3, 100, 210, 1, "kitti", "iid"),        # ragged: partial tiles
+    (12, 256, 832, 2, "kitti", "smooth"),    # configs[1] / [2] per-GPU workload
+    (4, 256, 320, 4, "nyu", "smooth"),       # configs[4]: NYU intrinsics, 4 refs
+])
+def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth):
+    from oracle import scsfm_oracle as O
+    from scsfm_hip import synth
+    d = synth.make_batch(B, H, W, n_ref=n_ref, seed=17, depth=depth, image="smooth" if depth == "smooth" else "iid",
+                         dataset=dataset)
+    flags = (1, 1, 1, "zeros")
+
+    def run(device, fn_pg, fn_s):
+        mv = lambda t: t.to(device).clone().requires_grad_(True)
+        td = [mv(t) for t in d["tgt_depth"]]
+        rd = [[mv(t) for t in r] for r in d["ref_depths"]]
+        ps, pi = [mv(p) for p in d["poses"]], [mv(p) for p in d["poses_inv"]]
+        tgt, refs, K = d["tgt_img"].to(device), [r.to(device) for r in d["ref_imgs"]], d["intrinsics"].to(device)
+        photo, geom = fn_pg(tgt, refs, K, td, rd, ps, pi, 1, *flags)
+        smooth = fn_s(td, tgt, rd, refs)
+        (photo + 0.1 * smooth + 0.5 * geom).backward()
+        grads = [td[0].grad] + [r[0].grad for r in rd] + [p.grad for p in ps + pi]
+        return [float(photo), float(geom), float(smooth)], grads
+
+    vh, gh = run(dev, LF.compute_photo_and_geometry_loss, LF.compute_smooth_loss)
+    vo, go = run("cpu", O.photo_and_geometry_loss, O.smooth_loss)
+    for a, b, nm in zip(vh, vo, ("photo", "geom", "smooth")):
+        assert abs(a - b) <= 1e-5 * max(1, n_ref / 2), (nm, a, b)  # photo/geom are sums over 2*n_ref pair terms
+    for a, b in zip(gh[:1 + n_ref], go[:1 + n_ref]):
+        _scale_close(a, b.numpy(), rel=5e-3, bad=2e-3, what="depth grad")
+    for a, b in zip(gh[1 + n_ref:], go[1 + n_ref:]):
+        _scale_close(a, b.numpy(), rel=5e-3, bad=0.0, what="pose grad")
+
+
+# ------------------------------------------------------------------------------------------------
+# 3. size-independent properties at full size
+# ------------------------------------------------------------------------------------------------
+def _full(dev, seed=3, B=12):
+    from scsfm_hip import synth
+    d = synth.make_batch(B, 256, 832, n_ref=1, seed=seed, depth="smooth")
+    return [t.to(dev).contiguous() for t in (d["tgt_img"], d["ref_imgs"][0], d["tgt_depth"][0],
+                                             d["ref_depths"][0][0], d["poses"][0], d["intrinsics"])]
+
+
+def test_sums_are_additive_over_batch_shards(dev):
+    """Checksum of checksums: the three raw sums of a batch equal the sums over its two halves (this is
+    also what the exact data-parallel mode relies on)."""
+    from scsfm_hip import _lib, capi
+    lib = _lib.get()
+    a = _full(dev)
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    whole, _ = capi.pair_fwd(lib, *a, fl)
+    lo, _ = capi.pair_fwd(lib, *[t[:6].contiguous() for t in a], fl)
+    hi, _ = capi.pair_fwd(lib, *[t[6:].contiguous() for t in a], fl)
+    assert float(whole[4]) == float(lo[4]) + float(hi[4])  # mask counts are integers: exact
+    for k in (2, 3):
+        assert abs(float(whole[k]) - float(lo[k]) - float(hi[k])) <= 2e-6 * abs(float(whole[k]))
+
+
+def test_forward_is_deterministic_and_backward_linear(dev):
+    from scsfm_hip import _lib, capi
+    lib = _lib.get()
+    a = _full(dev, seed=4)
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    o1, ws = capi.pair_fwd(lib, *a, fl)
+    o2, _ = capi.pair_fwd(lib, *a, fl)
+    assert torch.equal(o1, o2)  # per-block partials + ordered fp64 finalize: bit-reproducible
+    one = torch.ones(1, device=dev)
+    g1 = capi.pair_bwd(lib, *a, fl, ws, one, one)
+    g2 = capi.pair_bwd(lib, *a, fl, ws, 2 * one, 2 * one)
+    gp = capi.pair_bwd(lib, *a, fl, ws, one, 0 * one)
+    gg = capi.pair_bwd(lib, *a, fl, ws, 0 * one, one)
+    for x1, x2, xp, xg in zip(g1, g2, gp, gg):
+        s = float(x1.abs().max())
+        assert float((x2 - 2 * x1).abs().max()) <= 1e-4 * s       # homogeneity (atomics reorder sums)
+        assert float((xp + xg - x1).abs().max()) <= 1e-4 * s      # additivity in the two upstream gradients
+
+
+def test_batch_permutation_equivariance(dev):
+    from scsfm_hip import _lib, capi
+    lib = _lib.get()
+    a = _full(dev, seed=5, B=4)
+    perm = torch.tensor([2, 0, 3, 1], device=dev)
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    one = torch.ones(1, device=dev)
+    o, ws = capi.pair_fwd(lib, *a, fl)
+    g = capi.pair_bwd(lib, *a, fl, ws, one, one)
+    ap = [t[perm].contiguous() for t in a]
+    op, wsp = capi.pair_fwd(lib, *ap, fl)
+    gp = capi.pair_bwd(lib, *ap, fl, wsp, one, one)
+    assert float(o[4]) == float(op[4]) and abs(float(o[0]) - float(op[0])) <= 1e-6
+    assert float((g[0][perm] - gp[0]).abs().max()) <= 1e-6 * float(g[0].abs().max()) + 1e-12
+    assert float((g[2][perm] - gp[2]).abs().max()) <= 1e-4 * float(g[2].abs().max())
+
+
+# ------------------------------------------------------------------------------------------------
+# 4. boundary behaviour
+# ------------------------------------------------------------------------------------------------
+def test_error_behaviour_matches_the_reference(LF, IW, dev):
+    from scsfm_hip import synth
+    d = synth.make_batch(2, 32, 64, n_ref=1, seed=0)
+    img, dep, pose, K = (d["tgt_img"].to(dev), d["tgt_depth"][0].to(dev), d["poses"][0].to(dev), d["intrinsics"].to(dev))
+    with pytest.raises(AssertionError, match="wrong size for depth, expected Bx1xHxW"):
+        IW.inverse_warp2(img, dep.squeeze(1), dep, pose, K)  # check_sizes, inverse_warp.py:20-26
+    with pytest.raises(AssertionError, match="wrong size for pose"):
+        IW.inverse_warp2(img, dep, dep, pose[:, :5], K)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        LF.compute_pairwise_loss(img.cpu(), img.cpu(), dep.cpu(), dep.cpu(), pose.cpu(), K.cpu(), 1, 1, 1, "zeros")
+
+
+def test_ssim_module_and_mean_on_mask(LF, dev):
+    from oracle import scsfm_oracle as O
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 3, 64, 96, generator=g)
+    y = (x + 0.3 * torch.rand(2, 3, 64, 96, generator=g)).contiguous()
+    xd, yd = _leaf(x, dev), _leaf(y, dev)
+    out = LF.compute_ssim_loss(xd, yd)
+    w = torch.rand(2, 3, 64, 96, generator=g)
+    (out * w.to(dev)).sum().backward()
+    xc, yc = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    oc = O.ssim_map(xc, yc)
+    (oc * w).sum().backward()
+    assert float((out.cpu() - oc).abs().max()) <= 3e-5
+    _scale_close(xd.grad, xc.grad.numpy(), rel=1e-3, bad=1e-3)
+    _scale_close(yd.grad, yc.grad.numpy(), rel=1e-3, bad=1e-3)
+    diff = torch.rand(2, 3, 80, 112, generator=g)
+    mask = (torch.rand(2, 1, 80, 112, generator=g) > 0.3).float()
+    dd = _leaf(diff, dev)
+    m = LF.mean_on_mask(dd, mask.to(dev))
+    m.backward()
+    dc = diff.clone().requires_grad_(True)
+    mc = O.mean_on_mask(dc, mask)
+    mc.backward()
+    assert abs(float(m) - float(mc)) <= 1e-6
+    assert float((dd.grad.cpu() - dc.grad).abs().max()) <= 1e-9
+    small = LF.mean_on_mask(dd[:, :, :20, :20].contiguous(), mask[:, :, :20, :20].contiguous().to(dev))
+    assert float(small) == 0.0  # 800 pixels x 3 channels: below the 10000 gate
+
+
+def test_legacy_inverse_warp(IW, dev):
+    from oracle import scsfm_oracle as O
+    from scsfm_hip import synth
+    d = synth.make_batch(2, 64, 96, n_ref=1, seed=9)
+    img, dep, pose, K = d["ref_imgs"][0], d["tgt_depth"][0], d["poses"][0], d["intrinsics"]
+    w, valid = IW.inverse_warp(img.to(dev), dep.squeeze(1).to(dev), pose.to(dev), K.to(dev), "euler", "zeros")
+    # oracle: the legacy path has no coordinate overwrite -> same as 'border'-style projection with zero padding
+    Kinv = O.inv3x3(K, "explicit")
+    cam = O.back_project(dep.squeeze(1), Kinv)
+    P = K @ O.pose_vec2mat(pose)
+    xn, yn, _ = O.project(cam, P[:, :, :3], P[:, :, 3:], "border")  # 'border' = no overwrite
+    ow = O.bilinear_sample(img, xn, yn, "zeros", "explicit")
+    ov = torch.maximum(xn.abs(), yn.abs()) <= 1
+    assert (valid.cpu() != ov).double().mean() <= 1e-3
+    assert_close_frac(w.cpu().numpy(), ow.numpy(), atol=3e-4, max_bad_frac=2e-3)
