@@ -71,45 +71,46 @@ def hot_path_step(LF, x, flags):
     return loss, photo, smooth, geom
 
 
+def _event_time(fn, iters):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3  # seconds per call
+
+
 def time_kernels(x, flags, iters):
-    """Average launch duration (HIP events on the launching stream = torch's current stream) of the
-    pair forward and pair backward entry points, one pair-direction each."""
+    """Average duration (HIP events on the launching stream = torch's current stream) of the C-ABI
+    entry points of one pair-direction and one smooth-loss frame.  The two backward kernels are also
+    timed alone through the ABI's debug stage mask; those figures still contain the ~5 us
+    pose_bwd_kernel launch that follows them, i.e. they over- rather than under-state the kernel."""
     from scsfm_hip import _lib, capi
     lib = _lib.get()
     fl = capi.make_flags(*flags)
     a = (x["tgt_img"], x["ref_imgs"][0], x["tgt_depth"][0].detach(), x["ref_depths"][0][0].detach(),
          x["poses"][0].detach(), x["K"])
+    B, _, H, W = a[0].shape
     out, ws = capi.pair_fwd(lib, *a, fl)
     one = torch.ones(1, device=a[0].device)
     g_t, g_r = torch.zeros_like(a[2]), torch.zeros_like(a[3])
-    res = {}
-    for name, fn in (("pair_fwd", lambda: capi.pair_fwd_into(lib, *a, fl, out)),
-                     ("pair_bwd", lambda: capi.pair_bwd(lib, *a, fl, ws, one, one, g_t, g_r))):
-        for _ in range(5):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        res[name] = e0.elapsed_time(e1) / iters * 1e-3  # seconds per launch
+    scratch = capi.pair_bwd_scratch(lib, a[0], B, H, W)
     dep, img = x["tgt_depth"][0].detach(), x["tgt_img"]
     so, sws = capi.smooth_fwd(lib, dep, img)
-    for name, fn in (("smooth_fwd", lambda: capi.smooth_fwd(lib, dep, img, so)),
-                     ("smooth_bwd", lambda: capi.smooth_bwd(lib, dep, img, sws, one, g_t))):
-        for _ in range(5):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        res[name] = e0.elapsed_time(e1) / iters * 1e-3
-    return res
+    SKIP_PHOTO, SKIP_GEOM = 256, 512
+    calls = {
+        "pair_fwd": lambda: capi.pair_fwd_into(lib, *a, fl, out),
+        "pair_bwd": lambda: capi.pair_bwd(lib, *a, fl, ws, one, one, g_t, g_r, scratch),
+        "pair_bwd_photo_only": lambda: capi.pair_bwd(lib, *a, fl | SKIP_GEOM, ws, one, one, g_t, g_r, scratch),
+        "pair_bwd_geom_only": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO, ws, one, one, g_t, g_r, scratch),
+        "smooth_fwd": lambda: capi.smooth_fwd(lib, dep, img, so),
+        "smooth_bwd": lambda: capi.smooth_bwd(lib, dep, img, sws, one, g_t),
+    }
+    return {k: _event_time(fn, iters) for k, fn in calls.items()}
 
 
 def cpu_baseline(args, flags, budget_s):
@@ -120,7 +121,13 @@ def cpu_baseline(args, flags, budget_s):
     B = min(4, args.batch)
     d = synth.make_batch(B, args.height, args.width, n_ref=args.n_ref, seed=0, depth=args.depth,
                          image="smooth" if args.depth == "smooth" else "iid", dataset=args.dataset)
-    cores = os.cpu_count() or 1
+    # intra-op threads: the cores this process may use, capped -- the ATen CPU ops of this path stop
+    # scaling (and, oversubscribed, collapse) long before a 256-core host is filled
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, args.cpu_threads))
     torch.set_num_threads(cores)
 
     def one():
@@ -133,10 +140,12 @@ def cpu_baseline(args, flags, budget_s):
         smooth = O.smooth_loss(td, d["tgt_img"], rd, d["ref_imgs"])
         (W_PHOTO * photo + W_SMOOTH * smooth + W_GEOM * geom).backward()
 
+    t0 = time.perf_counter()
     one()  # warm-up
+    warm = time.perf_counter() - t0
     times = []
-    t_end = time.perf_counter() + budget_s
-    while time.perf_counter() < t_end or len(times) < 3:
+    t_end = time.perf_counter() + max(0.0, budget_s - warm)
+    while time.perf_counter() < t_end or len(times) < 1:
         t0 = time.perf_counter()
         one()
         times.append(time.perf_counter() - t0)
@@ -162,6 +171,7 @@ def main():
     ap.add_argument("--depth", default="smooth", choices=["smooth", "iid"],
                     help="synthetic depth law: smooth = realistic locality (headline), iid = incoherent gathers")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="cap on the CPU baseline's intra-op threads")
     ap.add_argument("--kernel-iters", type=int, default=30)
     args = ap.parse_args()
 
@@ -214,11 +224,19 @@ def main():
     value = world * args.batch * args.steps / elapsed
 
     kt = time_kernels(x, flags, args.kernel_iters)
-    bwd_bytes = 48 * n_px  # one pair-direction backward launch: read 32 B/px, RMW 16 B/px
-    achieved = bwd_bytes / kt["pair_bwd"] / 1e9
-    roofline = {"bound": "hbm", "kernel": "pair_bwd_kernel<float,true>", "achieved": round(achieved, 1),
+    # dominant kernel: the tiled backward pass.  Algorithmic bytes per launch: it must read both images
+    # and both depth maps once (32 B/px) and write dL/d(warped colours, diff_depth) once (16 B/px).
+    photo_bytes = 48 * n_px
+    achieved = photo_bytes / kt["pair_bwd_photo_only"] / 1e9
+    roofline = {"bound": "hbm", "kernel": "pair_bwd_photo_kernel<float,true>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_us": round(kt["pair_bwd"] * 1e6, 2)}
+                "algorithmic_bytes_per_launch": photo_bytes,
+                "avg_launch_us": round(kt["pair_bwd_photo_only"] * 1e6, 2)}
+    # SURVEY.md 8d figure for a whole pair-direction (forward + backward): 48 B/px
+    pair_t = kt["pair_fwd"] + kt["pair_bwd"]
+    pair_roofline = {"algorithmic_bytes": 48 * n_px, "us": round(pair_t * 1e6, 2),
+                     "achieved_GBs": round(48 * n_px / pair_t / 1e9, 1),
+                     "frac": round(48 * n_px / pair_t / 1e9 / HBM_PEAK_GBS, 4)}
     # sum of the kernel launches of one step, from the per-entry-point event timings
     kernel_sum = args.n_ref * 2 * (kt["pair_fwd"] + kt["pair_bwd"]) + (1 + args.n_ref) * (kt["smooth_fwd"] + kt["smooth_bwd"])
 
@@ -240,6 +258,7 @@ def main():
             "kernel_sum_ms_per_step": round(kernel_sum * 1e3, 4),
             "losses": {"total": loss, "photo": photo, "smooth": smooth, "geometry": geom},
             "roofline": roofline,
+            "pair_direction_roofline": pair_roofline,
         }
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(args, flags, args.cpu_seconds)

@@ -35,6 +35,9 @@ extern "C" {
 #define SCSFM_LEGACY_GRID 16u   /* warp entry points only: no zeros-mode coordinate overwrite, as the
                                    legacy inverse_warp / cam2pixel (inverse_warp.py:47-74,157-191) */
 
+#define SCSFM_DEBUG_SKIP_PHOTO 256u /* scsfm_pair_bwd only, for per-kernel timing: skip the tiled pass */
+#define SCSFM_DEBUG_SKIP_GEOM 512u  /* scsfm_pair_bwd only, for per-kernel timing: skip the per-pixel pass */
+
 #define SCSFM_ROT_EULER 0 /* inverse_warp.py:77-112  */
 #define SCSFM_ROT_QUAT 1  /* inverse_warp.py:115-136 */
 
@@ -59,20 +62,25 @@ int scsfm_abi_version(void);
  * scsfm_pair_refinalize : data-parallel exact mode -- after the caller has all-reduced out[2..4]
  *                       over the ranks, recompute out[0..1] and the backward coefficients in `ws`
  *                       from the global sums (the masked means are ratios of whole-batch sums).
- * scsfm_pair_bwd      : g_photo / g_geom are device scalars (upstream gradients of the two losses).
+ * scsfm_pair_bwd      : `scratch` = scsfm_pair_bwd_scratch_bytes(B,H,W) bytes of device memory, contents
+ *                       irrelevant before and after the call (it carries dL/d warped colours and
+ *                       dL/d diff_depth between the two backward kernels); may be shared by
+ *                       consecutive calls on one stream.
+ *                       g_photo / g_geom are device scalars (upstream gradients of the two losses).
  *                       g_tgt_depth [B,1,H,W] accumulate (dense), g_ref_depth [B,1,H,W] accumulate
  *                       (atomic scatter of the bilinear taps), g_pose [B,6] store.
  * --------------------------------------------------------------------------------------------- */
 size_t scsfm_pair_ws_bytes(int B, int H, int W);
+size_t scsfm_pair_bwd_scratch_bytes(int B, int H, int W);
 
 int scsfm_pair_fwd_f32(int B, int H, int W, const float* tgt_img, const float* ref_img,
                        const float* tgt_depth, const float* ref_depth, const float* pose,
                        const float* intrinsics, unsigned flags, void* ws, float* out, void* stream);
 int scsfm_pair_bwd_f32(int B, int H, int W, const float* tgt_img, const float* ref_img,
                        const float* tgt_depth, const float* ref_depth, const float* pose,
-                       const float* intrinsics, unsigned flags, void* ws, const float* g_photo,
-                       const float* g_geom, float* g_tgt_depth, float* g_ref_depth, float* g_pose,
-                       void* stream);
+                       const float* intrinsics, unsigned flags, void* ws, void* scratch,
+                       const float* g_photo, const float* g_geom, float* g_tgt_depth,
+                       float* g_ref_depth, float* g_pose, void* stream);
 int scsfm_pair_refinalize_f32(int B, int H, int W, void* ws, float* out, void* stream);
 int scsfm_pair_refinalize_f64(int B, int H, int W, void* ws, double* out, void* stream);
 int scsfm_pair_fwd_f64(int B, int H, int W, const double* tgt_img, const double* ref_img,
@@ -80,9 +88,9 @@ int scsfm_pair_fwd_f64(int B, int H, int W, const double* tgt_img, const double*
                        const double* intrinsics, unsigned flags, void* ws, double* out, void* stream);
 int scsfm_pair_bwd_f64(int B, int H, int W, const double* tgt_img, const double* ref_img,
                        const double* tgt_depth, const double* ref_depth, const double* pose,
-                       const double* intrinsics, unsigned flags, void* ws, const double* g_photo,
-                       const double* g_geom, double* g_tgt_depth, double* g_ref_depth,
-                       double* g_pose, void* stream);
+                       const double* intrinsics, unsigned flags, void* ws, void* scratch,
+                       const double* g_photo, const double* g_geom, double* g_tgt_depth,
+                       double* g_ref_depth, double* g_pose, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * inverse_warp2 (inverse_warp.py:230-269) as maps: projected_img [B,3,H,W], valid_mask [B,1,H,W]

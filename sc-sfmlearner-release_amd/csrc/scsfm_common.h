@@ -48,6 +48,12 @@ struct PairWs {
   int nbx, nby;
 };
 
+// hipGetLastError() reports the last error of ANY earlier runtime call of this thread (observed: a
+// stale hipErrorNoDevice left behind before the first launch), so entry points clear it first and
+// only report what their own launches produced.
+inline void clear_status() { (void)hipGetLastError(); }
+inline int launch_status() { return (int)hipGetLastError(); }
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 inline PairWs pair_ws_layout(int B, int H, int W) {
@@ -65,21 +71,24 @@ inline PairWs pair_ws_layout(int B, int H, int W) {
 // ------------------------------------------------------------------------------------------
 // Wave / block reductions (wave = 64 lanes).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
+// Sum over the 64 lanes of a wave.  Within a wave the working type is kept (fp32 on the product
+// path: 64 addends, ~1e-7 relative); across waves and blocks everything is carried in fp64.
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
   for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
 
-// Sum N doubles per thread over the whole block; result valid in thread 0.  `scratch` must hold
-// N * (kThreads / kWave) doubles.
-template <int N>
-__device__ __forceinline__ void block_sum(double (&v)[N], double* scratch) {
+// Sum N values per thread over the whole block; the result replaces v[] in thread 0 (other threads
+// keep their own partial values).  `scratch` must hold N * (kThreads / kWave) doubles.
+template <int N, typename T>
+__device__ __forceinline__ void block_sum(T (&v)[N], double* scratch) {
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    double s = wave_sum(v[i]);
-    if (lane == 0) scratch[wave * N + i] = s;
+    const T s = wave_sum(v[i]);
+    if (lane == 0) scratch[wave * N + i] = double(s);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -87,7 +96,7 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double* scratch) {
     for (int i = 0; i < N; ++i) {
       double s = 0;
       for (int w = 0; w < kThreads / kWave; ++w) s += scratch[w * N + i];
-      v[i] = s;
+      v[i] = T(s);
     }
   }
 }
@@ -110,6 +119,10 @@ __device__ __forceinline__ float t_exp(float x) { return expf(x); }
 __device__ __forceinline__ double t_exp(double x) { return exp(x); }
 __device__ __forceinline__ void t_sincos(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
 __device__ __forceinline__ void t_sincos(double x, double* s, double* c) { *s = sin(x); *c = cos(x); }
+// reciprocal: v_rcp_f32 (1 ulp) on the fp32 product path, exact division for the fp64 check path
+__device__ __forceinline__ float t_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double t_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ int t_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 __device__ __forceinline__ float t_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double t_sqrt(double x) { return sqrt(x); }
 

@@ -100,11 +100,13 @@ __global__ void prep_kernel(int B, const T* __restrict__ pose, const T* __restri
 // gP = dL/d(A|c) [B][12] (fp64 accumulators) -> dL/dpose [B,6]:  gT = K^T gP, then the euler chain.
 template <typename T>
 __global__ void pose_bwd_kernel(int B, const T* __restrict__ pose, const T* __restrict__ K,
-                                const double* __restrict__ gP, T* __restrict__ gpose) {
+                                double* __restrict__ gP, T* __restrict__ gpose) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const T* k = K + 9 * b;
-  const double* g = gP + 12 * b;
+  double g[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { g[i] = gP[12 * b + i]; gP[12 * b + i] = 0.0; }  // consumed: ready for the next backward
   T gR[9], gt[3];
 #pragma unroll
   for (int kk = 0; kk < 3; ++kk) {
@@ -130,8 +132,10 @@ struct Sample {
   T X, Y, Zraw, Z;  // A cam + c ; Z = max(Zraw, 1e-3) is the "computed depth"
   T fx, fy;         // bilinear fractions (distance to the west / north tap)
   T gmx, gmy;       // d ix / d xn (= W/2), zeroed by the zeros-mode overwrite or the border clip
-  int x0, y0;       // north-west tap
-  unsigned inb;     // bit k: tap k (0 nw, 1 ne, 2 sw, 3 se) lies inside the image
+  T w[4];           // bilinear weights of the taps (0 nw, 1 ne, 2 sw, 3 se); 0 for taps outside the image
+  unsigned off[4];  // element offset of each tap inside a plane, clamped into the image so that the
+                    // four loads need no predication (their weight is 0 when they were clamped)
+  unsigned inb;     // bit k: tap k lies inside the image
   bool valid;       // max(|xn|, |yn|) <= 1   (inverse_warp.py:264)
 };
 
@@ -151,8 +155,11 @@ __device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int
   s.Y = bc.A[3] * cx + bc.A[4] * cy + bc.A[5] * cz + bc.c[1];
   s.Zraw = bc.A[6] * cx + bc.A[7] * cy + bc.A[8] * cz + bc.c[2];
   s.Z = t_max(s.Zraw, T(kZMin));
-  T xn = T(2) * (s.X / s.Z) / T(W - 1) - T(1);
-  T yn = T(2) * (s.Y / s.Z) / T(H - 1) - T(1);
+  // xn = 2 (X/Z)/(W-1) - 1 (inverse_warp.py:217-218); the two divisions are a reciprocal of Z and a
+  // per-launch constant (1-2 ulp from the reference's correctly rounded quotients)
+  const T iz = t_rcp(s.Z);
+  T xn = (s.X * iz) * (T(2) / T(W - 1)) - T(1);
+  T yn = (s.Y * iz) * (T(2) / T(H - 1)) - T(1);
   s.gmx = T(0.5) * T(W);
   s.gmy = T(0.5) * T(H);
   if (overwrite) {  // inverse_warp.py:219-224: out-of-range coordinates become the constant 2
@@ -173,34 +180,50 @@ __device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int
   const T fx0 = t_floor(ix), fy0 = t_floor(iy);
   s.fx = ix - fx0;
   s.fy = iy - fy0;
-  s.x0 = int(fx0);
-  s.y0 = int(fy0);
-  const bool xw = s.x0 >= 0 && s.x0 < W, xe = s.x0 + 1 >= 0 && s.x0 + 1 < W;
-  const bool yn_ = s.y0 >= 0 && s.y0 < H, ys = s.y0 + 1 >= 0 && s.y0 + 1 < H;
+  const int x0 = int(fx0), y0 = int(fy0), x1 = x0 + 1, y1 = y0 + 1;
+  const bool xw = x0 >= 0 && x0 < W, xe = x1 >= 0 && x1 < W;
+  const bool yn_ = y0 >= 0 && y0 < H, ys = y1 >= 0 && y1 < H;
   s.inb = (xw && yn_ ? 1u : 0u) | (xe && yn_ ? 2u : 0u) | (xw && ys ? 4u : 0u) | (xe && ys ? 8u : 0u);
+  // ATen CPU kernel: nw = s*e, ne = s*w, sw = n*e, se = n*w with w = fx, e = 1-fx, n = fy, s = 1-fy
+  const T e = T(1) - s.fx, so = T(1) - s.fy;
+  const T wx0 = xw ? e : T(0), wx1 = xe ? s.fx : T(0), wy0 = yn_ ? so : T(0), wy1 = ys ? s.fy : T(0);
+  s.w[0] = wy0 * wx0; s.w[1] = wy0 * wx1; s.w[2] = wy1 * wx0; s.w[3] = wy1 * wx1;
+  const int xc0 = t_clampi(x0, 0, W - 1), xc1 = t_clampi(x1, 0, W - 1);
+  const int r0 = t_clampi(y0, 0, H - 1) * W, r1 = t_clampi(y1, 0, H - 1) * W;
+  s.off[0] = unsigned(r0 + xc0); s.off[1] = unsigned(r0 + xc1);
+  s.off[2] = unsigned(r1 + xc0); s.off[3] = unsigned(r1 + xc1);
   return s;
 }
 
-// The four taps of one plane (out-of-image taps read as 0, which is also what the gradient of
-// grid_sampler_2d with respect to the coordinates assumes).
+// The four taps of one plane.  Unpredicated: clamped addresses, zero weights for clamped taps.
 template <typename T>
-__device__ __forceinline__ void load_taps(const T* __restrict__ plane, const Sample<T>& s, int W, T* v) {
-  const long base = (long)s.y0 * W + s.x0;
-  v[0] = (s.inb & 1u) ? plane[base] : T(0);
-  v[1] = (s.inb & 2u) ? plane[base + 1] : T(0);
-  v[2] = (s.inb & 4u) ? plane[base + W] : T(0);
-  v[3] = (s.inb & 8u) ? plane[base + W + 1] : T(0);
+__device__ __forceinline__ void load_taps(const T* __restrict__ plane, const Sample<T>& s, T* v) {
+  v[0] = plane[s.off[0]]; v[1] = plane[s.off[1]]; v[2] = plane[s.off[2]]; v[3] = plane[s.off[3]];
 }
 
 template <typename T>
-__device__ __forceinline__ T bilerp(const T* v, T fx, T fy) {
-  const T e = T(1) - fx, so = T(1) - fy;  // ATen CPU kernel: nw = s*e, ne = s*w, sw = n*e, se = n*w
-  return v[0] * (so * e) + v[1] * (so * fx) + v[2] * (fy * e) + v[3] * (fy * fx);
+__device__ __forceinline__ T bilerp(const T* v, const Sample<T>& s) {
+  return v[0] * s.w[0] + v[1] * s.w[1] + v[2] * s.w[2] + v[3] * s.w[3];
+}
+
+// d(sample)/d(ix, iy): out-of-image taps count as the value 0 (what grid_sampler_2d_backward does for
+// the coordinate gradient), so the loaded (clamped) values are masked first.
+template <typename T>
+struct SampleGrad {
+  T cx[4], cy[4];
+};
+template <typename T>
+__device__ __forceinline__ SampleGrad<T> sample_grad(const Sample<T>& s) {
+  SampleGrad<T> g;
+  const T m0 = (s.inb & 1u) ? T(1) : T(0), m1 = (s.inb & 2u) ? T(1) : T(0);
+  const T m2 = (s.inb & 4u) ? T(1) : T(0), m3 = (s.inb & 8u) ? T(1) : T(0);
+  const T e = T(1) - s.fx, so = T(1) - s.fy;
+  g.cx[0] = -so * m0; g.cx[1] = so * m1; g.cx[2] = -s.fy * m2; g.cx[3] = s.fy * m3;
+  g.cy[0] = -e * m0; g.cy[1] = -s.fx * m1; g.cy[2] = e * m2; g.cy[3] = s.fx * m3;
+  return g;
 }
 template <typename T>
-__device__ __forceinline__ T bilerp_dx(const T* v, T fx, T fy) { return (v[1] - v[0]) * (T(1) - fy) + (v[3] - v[2]) * fy; }
-template <typename T>
-__device__ __forceinline__ T bilerp_dy(const T* v, T fx, T fy) { return (v[2] - v[0]) * (T(1) - fx) + (v[3] - v[1]) * fx; }
+__device__ __forceinline__ T dot4(const T* v, const T* c) { return v[0] * c[0] + v[1] * c[1] + v[2] * c[2] + v[3] * c[3]; }
 
 // Gradient of one pixel's sampling position back to the target depth and to A|c.
 //   gix, giy : dL/d(ix, iy) (un-normalised sampling coordinates)
@@ -212,7 +235,7 @@ __device__ __forceinline__ T pixel_geometry_bwd(const BatchConsts<T>& bc, const 
   // ix = ((xn+1) W - 1)/2, xn = 2 (X/Z)/(W-1) - 1   (inverse_warp.py:217-218)
   const T gqx = gix * s.gmx * (T(2) / T(W - 1));
   const T gqy = giy * s.gmy * (T(2) / T(H - 1));
-  const T iz = T(1) / s.Z;
+  const T iz = t_rcp(s.Z);
   const T dX = gqx * iz;
   const T dY = gqy * iz;
   // Z = clamp(Zraw, min=1e-3): gradient passes where Zraw >= 1e-3 (inverse_warp.py:211)
@@ -231,14 +254,12 @@ __device__ __forceinline__ T pixel_geometry_bwd(const BatchConsts<T>& bc, const 
 // Scatter dL/d(projected depth) of one pixel into the gradient of the sampled depth map
 // (grid_sampler_2d_backward on the input; only in-image taps receive anything).
 template <typename T>
-__device__ __forceinline__ void scatter_taps(T* __restrict__ gplane, const Sample<T>& s, int W, T g) {
+__device__ __forceinline__ void scatter_taps(T* __restrict__ gplane, const Sample<T>& s, T g) {
   if (g == T(0)) return;
-  const T e = T(1) - s.fx, so = T(1) - s.fy;
-  const long base = (long)s.y0 * W + s.x0;
-  if (s.inb & 1u) atomicAdd(gplane + base, g * (so * e));
-  if (s.inb & 2u) atomicAdd(gplane + base + 1, g * (so * s.fx));
-  if (s.inb & 4u) atomicAdd(gplane + base + W, g * (s.fy * e));
-  if (s.inb & 8u) atomicAdd(gplane + base + W + 1, g * (s.fy * s.fx));
+  if (s.inb & 1u) atomicAdd(gplane + s.off[0], g * s.w[0]);
+  if (s.inb & 2u) atomicAdd(gplane + s.off[1], g * s.w[1]);
+  if (s.inb & 4u) atomicAdd(gplane + s.off[2], g * s.w[2]);
+  if (s.inb & 8u) atomicAdd(gplane + s.off[3], g * s.w[3]);
 }
 
 }  // namespace scsfm

@@ -21,27 +21,37 @@
 
 namespace scsfm {
 
-// Warp one pixel (already reflected into the image): the three warped colours, the target
-// colours, and optionally everything else the loss needs at an owned pixel.
-template <typename T>
-struct PixelOut {
-  T Iw[3], It[3];
-};
-
+// Warp one pixel (already reflected into the image): the (target, warped) colour pairs.
 template <typename T>
 __device__ __forceinline__ Sample<T> warp_colours(const BatchConsts<T>& bc, int u, int v, int H, int W, unsigned flags,
                                                   const T* __restrict__ tgt_img, const T* __restrict__ ref_img,
-                                                  const T* __restrict__ tgt_depth, PixelOut<T>& o) {
-  const long plane = (long)H * W, p = (long)v * W + u;
+                                                  const T* __restrict__ tgt_depth, typename Vec2<T>::type* xy) {
+  const unsigned plane = unsigned(H) * unsigned(W), p = unsigned(v) * unsigned(W) + unsigned(u);
   const Sample<T> s = project_pixel(bc, u, v, tgt_depth[p], H, W, flags);
   T t[4];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    load_taps(ref_img + c * plane, s, W, t);
-    o.Iw[c] = bilerp(t, s.fx, s.fy);
-    o.It[c] = tgt_img[c * plane + p];
+    load_taps(ref_img + c * plane, s, t);
+    xy[c] = make2(tgt_img[c * plane + p], bilerp(t, s));
   }
   return s;
+}
+
+// Mask of an owned pixel: valid (inverse_warp.py:264), optionally AND auto-mask
+// (loss_functions.py:103-105: mean_c clamped |It - Iw| < mean_c |It - Ir|, same pixel, un-warped ref).
+// Both means share the divisor 3, so the sums are compared.
+template <typename T>
+__device__ __forceinline__ T pixel_mask(const Sample<T>& s, bool with_auto, const typename Vec2<T>::type* xy,
+                                        const T* __restrict__ ref_img, unsigned plane, unsigned p) {
+  T m = s.valid ? T(1) : T(0);
+  if (with_auto) {
+    const T ident = t_abs(xy[0][0] - ref_img[p]) + t_abs(xy[1][0] - ref_img[plane + p]) +
+                    t_abs(xy[2][0] - ref_img[2 * plane + p]);
+    const T warped = clamp01(t_abs(xy[0][0] - xy[0][1])) + clamp01(t_abs(xy[1][0] - xy[1][1])) +
+                     clamp01(t_abs(xy[2][0] - xy[2][1]));
+    m = (warped < ident) ? m : T(0);
+  }
+  return m;
 }
 
 // ==========================================================================================
@@ -52,53 +62,41 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(
     int H, int W, unsigned flags, const T* __restrict__ tgt_img, const T* __restrict__ ref_img,
     const T* __restrict__ tgt_depth, const T* __restrict__ ref_depth, const BatchConsts<T>* __restrict__ consts,
     double* __restrict__ partials) {
+  typedef typename Vec2<T>::type V2;
   constexpr int TH = Tile<T>::kH, STRIP = TH / (kThreads / kWave);
-  __shared__ T sIw[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];
-  __shared__ T sIt[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];
+  __shared__ V2 sXY[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];  // (target, warped) + 1-pixel ring
   __shared__ double red[3 * (kThreads / kWave)];
 
   const int b = blockIdx.z, col = threadIdx.x & (kWave - 1), strip = threadIdx.x / kWave;
   const int tx0 = blockIdx.x * kTileW, ty0 = blockIdx.y * TH;
-  const bool with_mask = (flags & SCSFM_WITH_MASK) != 0,
-             with_auto = (flags & SCSFM_WITH_AUTO_MASK) != 0;
+  const bool with_mask = (flags & SCSFM_WITH_MASK) != 0, with_auto = (flags & SCSFM_WITH_AUTO_MASK) != 0;
   const BatchConsts<T> bc = consts[b];
-  const long plane = (long)H * W;
-  tgt_img += (long)b * 3 * plane;
-  ref_img += (long)b * 3 * plane;
-  tgt_depth += (long)b * plane;
-  ref_depth += (long)b * plane;
+  const unsigned plane = unsigned(H) * unsigned(W);
+  tgt_img += (size_t)b * 3 * plane;
+  ref_img += (size_t)b * 3 * plane;
+  tgt_depth += (size_t)b * plane;
+  ref_depth += (size_t)b * plane;
 
-  T m[STRIP], dd[STRIP], l1[STRIP][3];
+  T m[STRIP], dd[STRIP], l1sum[STRIP];
   // ---- phase 1a: the pixels this thread owns -------------------------------------------------
 #pragma unroll
   for (int k = 0; k < STRIP; ++k) {
     const int ly = strip * STRIP + k, gx = tx0 + col, gy = ty0 + ly;
     const bool inimg = gx < W && gy < H;
     const int u = reflect_index(gx, W), v = reflect_index(gy, H);
-    PixelOut<T> o;
-    const Sample<T> s = warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, o);
+    V2 xy[3];
+    const Sample<T> s = warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, xy);
     if (kSsim) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { sIw[c][ly + 1][col + 1] = o.Iw[c]; sIt[c][ly + 1][col + 1] = o.It[c]; }
+      for (int c = 0; c < 3; ++c) sXY[c][ly + 1][col + 1] = xy[c];
     }
-    m[k] = T(0); dd[k] = T(0);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) l1[k][c] = clamp01(t_abs(o.It[c] - o.Iw[c]));  // loss_functions.py:99
-    if (inimg) {
-      T t[4];
-      load_taps(ref_depth, s, W, t);
-      const T Dp = bilerp(t, s.fx, s.fy);
-      dd[k] = clamp01(t_abs(s.Z - Dp) / (s.Z + Dp));  // loss_functions.py:101
-      T mk = s.valid ? T(1) : T(0);
-      if (with_auto) {  // loss_functions.py:103-105
-        const long p = (long)v * W + u;
-        const T ident = (t_abs(o.It[0] - ref_img[p]) + t_abs(o.It[1] - ref_img[plane + p]) +
-                         t_abs(o.It[2] - ref_img[2 * plane + p])) / T(3);
-        const T warped = (l1[k][0] + l1[k][1] + l1[k][2]) / T(3);
-        mk = (warped < ident) ? mk : T(0);
-      }
-      m[k] = mk;
-    }
+    l1sum[k] = clamp01(t_abs(xy[0][0] - xy[0][1])) + clamp01(t_abs(xy[1][0] - xy[1][1])) +
+               clamp01(t_abs(xy[2][0] - xy[2][1]));  // loss_functions.py:99, summed over colours
+    T t[4];
+    load_taps(ref_depth, s, t);
+    const T Dp = bilerp(t, s);
+    dd[k] = clamp01(t_abs(s.Z - Dp) * t_rcp(s.Z + Dp));  // loss_functions.py:101
+    m[k] = inimg ? pixel_mask(s, with_auto, xy, ref_img, plane, unsigned(v) * unsigned(W) + unsigned(u)) : T(0);
   }
   // ---- phase 1b: the 1-pixel ring (SSIM windows of the tile's border pixels) ------------------
   if (kSsim) {
@@ -106,45 +104,28 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(
       int hy, hx;
       ring_pos<TH>(threadIdx.x, hy, hx);
       const int u = reflect_index(tx0 + hx - 1, W), v = reflect_index(ty0 + hy - 1, H);
-      PixelOut<T> o;
-      warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, o);
+      V2 xy[3];
+      warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, xy);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { sIw[c][hy][hx] = o.Iw[c]; sIt[c][hy][hx] = o.It[c]; }
+      for (int c = 0; c < 3; ++c) sXY[c][hy][hx] = xy[c];
     }
     __syncthreads();
   }
   // ---- phase 2: SSIM down the strip, blend, weight, accumulate -------------------------------
-  T acc_p = T(0), acc_g = T(0), acc_m = T(0);
   T photo[STRIP];
 #pragma unroll
-  for (int k = 0; k < STRIP; ++k) photo[k] = T(0);
+  for (int k = 0; k < STRIP; ++k) photo[k] = kSsim ? T(0.15) * l1sum[k] : l1sum[k];  // loss_functions.py:109
+  if constexpr (kSsim) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    if (kSsim) {
-      T hx_[STRIP + 2], hy_[STRIP + 2], hxx[STRIP + 2], hyy[STRIP + 2], hxy[STRIP + 2];
+    for (int c = 0; c < 3; ++c) {
+      WinSums<T> ws[STRIP];
+      V2 centre[STRIP];
+      strip_window_sums<T, STRIP>(sXY[c], strip * STRIP, col, ws, centre);
 #pragma unroll
-      for (int r = 0; r < STRIP + 2; ++r) {
-        const int row = strip * STRIP + r;
-        const T x0 = sIt[c][row][col], x1 = sIt[c][row][col + 1], x2 = sIt[c][row][col + 2];
-        const T y0 = sIw[c][row][col], y1 = sIw[c][row][col + 1], y2 = sIw[c][row][col + 2];
-        hx_[r] = x0 + x1 + x2;
-        hy_[r] = y0 + y1 + y2;
-        hxx[r] = x0 * x0 + x1 * x1 + x2 * x2;
-        hyy[r] = y0 * y0 + y1 * y1 + y2 * y2;
-        hxy[r] = x0 * y0 + x1 * y1 + x2 * y2;
-      }
-#pragma unroll
-      for (int k = 0; k < STRIP; ++k) {
-        const SsimStats<T> st = ssim_stats(hx_[k] + hx_[k + 1] + hx_[k + 2], hy_[k] + hy_[k + 1] + hy_[k + 2],
-                                           hxx[k] + hxx[k + 1] + hxx[k + 2], hyy[k] + hyy[k + 1] + hyy[k + 2],
-                                           hxy[k] + hxy[k + 1] + hxy[k + 2]);
-        photo[k] += T(0.15) * l1[k][c] + T(0.85) * clamp01(st.raw);  // loss_functions.py:109
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < STRIP; ++k) photo[k] += l1[k][c];
+      for (int k = 0; k < STRIP; ++k) photo[k] += T(0.85) * clamp01(ssim_stats(ws[k]).raw);
     }
   }
+  T acc_p = T(0), acc_g = T(0), acc_m = T(0);
 #pragma unroll
   for (int k = 0; k < STRIP; ++k) {
     const T w = with_mask ? (T(1) - dd[k]) : T(1);  // loss_functions.py:111-113
@@ -152,11 +133,11 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(
     acc_g += dd[k] * m[k];
     acc_m += m[k];
   }
-  double v[3] = {double(acc_p), double(acc_g), double(acc_m)};
+  T v[3] = {acc_p, acc_g, acc_m};
   block_sum<3>(v, red);
   if (threadIdx.x == 0) {
-    double* o = partials + 3 * ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
-    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    double* o = partials + 3 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    o[0] = double(v[0]); o[1] = double(v[1]); o[2] = double(v[2]);
   }
 }
 
@@ -181,8 +162,11 @@ __device__ __forceinline__ void publish_losses(double Sp, double Sg, double Sm, 
 // the coefficients the backward multiplies the upstream gradients with.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(int nblocks, const double* __restrict__ partials,
-                                                                 double* __restrict__ sums, T* __restrict__ out) {
+                                                                 double* __restrict__ sums, T* __restrict__ out,
+                                                                 double* __restrict__ gP, int n_gP) {
   __shared__ double red[3 * (kThreads / kWave)];
+  // the backward accumulates dL/d(A|c) here with atomics; pose_bwd_kernel re-zeroes it after use
+  for (int i = threadIdx.x; i < n_gP; i += kThreads) gP[i] = 0.0;
   double v[3] = {0, 0, 0};
   for (int i = threadIdx.x; i < nblocks; i += kThreads) {
     v[0] += partials[3 * i]; v[1] += partials[3 * i + 1]; v[2] += partials[3 * i + 2];
@@ -200,213 +184,208 @@ __global__ void pair_refinalize_kernel(double* __restrict__ sums, T* __restrict_
 }
 
 // ==========================================================================================
-// Backward
+// Backward, pass A (tiled): dL/d(warped colours) and dL/d(diff_depth) per pixel.
+//
+// Recomputes the warp inside the tile (nothing but 3 sums is kept from the forward), runs the SSIM
+// backward -- forward statistics at every pixel of the 64 x TH domain, then the transpose of
+// (reflect-pad + box) as a separable 3x3 gather -- and writes four planes for the 62 x (TH-2)
+// interior: gbuf[c] = dL/dI_w,c (c = 0..2), gbuf[3] = dL/d diff_depth.  Pass B consumes them.
+// Splitting here keeps both halves at a register budget that sustains >= 4 waves per SIMD; fused,
+// the kernel needed 256 VGPRs (1 wave per SIMD) and could not hide its gather latency.
 // ==========================================================================================
 template <typename T, bool kSsim>
-__global__ __launch_bounds__(kThreads) void pair_bwd_kernel(
+__global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
     int H, int W, unsigned flags, const T* __restrict__ tgt_img, const T* __restrict__ ref_img,
     const T* __restrict__ tgt_depth, const T* __restrict__ ref_depth, const BatchConsts<T>* __restrict__ consts,
     const double* __restrict__ sums, const T* __restrict__ g_photo, const T* __restrict__ g_geom,
-    T* __restrict__ g_tgt_depth, T* __restrict__ g_ref_depth, double* __restrict__ gP) {
+    T* __restrict__ gbuf) {
+  typedef typename Vec2<T>::type V2;
   constexpr int TH = Tile<T>::kH, STRIP = TH / (kThreads / kWave);
-  __shared__ T sIw[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];
-  __shared__ T sIt[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];
-  __shared__ T sG[kSsim ? 3 : 1][kSsim ? TH : 1][kSsim ? kTileW : 1];
-  __shared__ double red[12 * (kThreads / kWave)];
+  __shared__ V2 sXY[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];
+  __shared__ T sG[kSsim ? 3 : 1][kSsim ? TH : 1][kSsim ? kTileW : 1];  // 1/9 (g_mu_y, g_E[y^2], g_E[xy]), one colour
 
   // upstream gradient x d(masked mean)/d(sum): zero when the 10000-pixel gate was closed
   const T a = T(sums[5]) * g_photo[0];
   const T bg = T(sums[6]) * g_geom[0];
-  if (a == T(0) && bg == T(0)) return;  // workgroup-uniform: nothing to propagate
+  if (a == T(0) && bg == T(0)) return;  // workgroup-uniform: pass B skips as well
 
   const int b = blockIdx.z, col = threadIdx.x & (kWave - 1), strip = threadIdx.x / kWave;
   // the 64 x TH compute domain starts one pixel before the 62 x (TH-2) block of outputs
   const int ox = blockIdx.x * (kTileW - 2) - 1, oy = blockIdx.y * (TH - 2) - 1;
-  const bool with_mask = (flags & SCSFM_WITH_MASK) != 0,
-             with_auto = (flags & SCSFM_WITH_AUTO_MASK) != 0;
+  const bool with_mask = (flags & SCSFM_WITH_MASK) != 0, with_auto = (flags & SCSFM_WITH_AUTO_MASK) != 0;
   const BatchConsts<T> bc = consts[b];
-  const long plane = (long)H * W;
-  tgt_img += (long)b * 3 * plane;
-  ref_img += (long)b * 3 * plane;
-  tgt_depth += (long)b * plane;
-  ref_depth += (long)b * plane;
-  g_tgt_depth += (long)b * plane;
-  g_ref_depth += (long)b * plane;
+  const unsigned plane = unsigned(H) * unsigned(W);
+  const size_t gplane = (size_t)gridDim.z * plane;  // one gbuf plane spans the whole batch
+  tgt_img += (size_t)b * 3 * plane;
+  ref_img += (size_t)b * 3 * plane;
+  tgt_depth += (size_t)b * plane;
+  ref_depth += (size_t)b * plane;
+  gbuf += (size_t)b * plane;
 
-  T coef[STRIP];             // a * m * (1 - dd): weight of blend_c(q) in the loss
-  T mq[STRIP], wq[STRIP];    // mask and (1 - dd) of the owned pixel
-  T dIx[STRIP][3], dIy[STRIP][3], l1s[STRIP][3];  // d I_w,c / d(ix, iy); -sgn(It - Iw) gated by the clamp
-  T l1v[STRIP][3];
-  T gix[STRIP], giy[STRIP], bsum[STRIP];
-  bool inimg[STRIP];
+  const int px = ox + col, py0 = oy + strip * STRIP;
+  const bool in_x = col >= 1 && col <= kTileW - 2 && px < W;
+  T coef[STRIP];  // a * m * (1 - dd): weight of blend_c(q) in the loss
+  T mq[STRIP];    // mask of the owned pixel
+  T bsum[STRIP];  // sum_c blend_c of the owned pixel
+  V2 cen[kSsim ? 1 : STRIP][kSsim ? 1 : 3];
   // ---- phase 1a ------------------------------------------------------------------------------
 #pragma unroll
   for (int k = 0; k < STRIP; ++k) {
-    const int ly = strip * STRIP + k, gx = ox + col, gy = oy + ly;
-    inimg[k] = gx >= 0 && gx < W && gy >= 0 && gy < H;
-    const int u = reflect_index(gx, W), v = reflect_index(gy, H);
-    const long p = (long)v * W + u;
-    const Sample<T> s = project_pixel(bc, u, v, tgt_depth[p], H, W, flags);
-    T t[4], Iw[3], It[3];
+    const int ly = strip * STRIP + k, py = py0 + k;
+    const bool inimg = px >= 0 && px < W && py >= 0 && py < H;
+    const int u = reflect_index(px, W), v = reflect_index(py, H);
+    V2 xy[3];
+    const Sample<T> s = warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, xy);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      load_taps(ref_img + c * plane, s, W, t);
-      Iw[c] = bilerp(t, s.fx, s.fy);
-      dIx[k][c] = bilerp_dx(t, s.fx, s.fy);
-      dIy[k][c] = bilerp_dy(t, s.fx, s.fy);
-      It[c] = tgt_img[c * plane + p];
-      const T d = It[c] - Iw[c];
-      l1v[k][c] = clamp01(t_abs(d));
-      // d clamp(|d|, 0, 1) / d Iw: the clamp passes gradient on [0, 1] inclusive, abs uses sgn
-      l1s[k][c] = (t_abs(d) <= T(1)) ? -t_sgn(d) : T(0);
-      if (kSsim) { sIw[c][ly + 1][col + 1] = Iw[c]; sIt[c][ly + 1][col + 1] = It[c]; }
+      if constexpr (kSsim) sXY[c][ly + 1][col + 1] = xy[c]; else cen[k][c] = xy[c];
     }
-    mq[k] = T(0); wq[k] = T(1); coef[k] = T(0);
-    gix[k] = T(0); giy[k] = T(0); bsum[k] = T(0);
-    if (inimg[k]) {
-      load_taps(ref_depth, s, W, t);
-      const T Dp = bilerp(t, s.fx, s.fy);
-      const T ddk = clamp01(t_abs(s.Z - Dp) / (s.Z + Dp));
-      T mk = s.valid ? T(1) : T(0);
-      if (with_auto) {
-        const T ident = (t_abs(It[0] - ref_img[p]) + t_abs(It[1] - ref_img[plane + p]) +
-                         t_abs(It[2] - ref_img[2 * plane + p])) / T(3);
-        const T warped = (l1v[k][0] + l1v[k][1] + l1v[k][2]) / T(3);
-        mk = (warped < ident) ? mk : T(0);
-      }
-      mq[k] = mk;
-      wq[k] = with_mask ? (T(1) - ddk) : T(1);
-      coef[k] = a * mk * wq[k];
-    }
+    T t[4];
+    load_taps(ref_depth, s, t);
+    const T Dp = bilerp(t, s);
+    const T ddk = clamp01(t_abs(s.Z - Dp) * t_rcp(s.Z + Dp));
+    mq[k] = inimg ? pixel_mask(s, with_auto, xy, ref_img, plane, unsigned(v) * unsigned(W) + unsigned(u)) : T(0);
+    coef[k] = a * mq[k] * (with_mask ? (T(1) - ddk) : T(1));
+    bsum[k] = T(0);
   }
   // ---- phase 1b: ring ------------------------------------------------------------------------
-  if (kSsim) {
+  if constexpr (kSsim) {
     if (threadIdx.x < 2 * kHaloW + 2 * TH) {
       int hy, hx;
       ring_pos<TH>(threadIdx.x, hy, hx);
       const int u = reflect_index(ox + hx - 1, W), v = reflect_index(oy + hy - 1, H);
-      PixelOut<T> o;
-      warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, o);
+      V2 xy[3];
+      warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, xy);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { sIw[c][hy][hx] = o.Iw[c]; sIt[c][hy][hx] = o.It[c]; }
+      for (int c = 0; c < 3; ++c) sXY[c][hy][hx] = xy[c];
     }
     __syncthreads();
   }
   // ---- phases 2/3, one colour channel at a time ------------------------------------------------
-  const int px = ox + col;
-  const bool in_x = col >= 1 && col <= kTileW - 2;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    if (kSsim) {
-      // phase 2: forward statistics at every owned pixel q; publish 1/9 * (g_mu_y, g_Eyy, g_Exy)(q)
-      T hx_[STRIP + 2], hy_[STRIP + 2], hxx[STRIP + 2], hyy[STRIP + 2], hxy[STRIP + 2];
-#pragma unroll
-      for (int r = 0; r < STRIP + 2; ++r) {
-        const int row = strip * STRIP + r;
-        const T x0 = sIt[c][row][col], x1 = sIt[c][row][col + 1], x2 = sIt[c][row][col + 2];
-        const T y0 = sIw[c][row][col], y1 = sIw[c][row][col + 1], y2 = sIw[c][row][col + 2];
-        hx_[r] = x0 + x1 + x2;
-        hy_[r] = y0 + y1 + y2;
-        hxx[r] = x0 * x0 + x1 * x1 + x2 * x2;
-        hyy[r] = y0 * y0 + y1 * y1 + y2 * y2;
-        hxy[r] = x0 * y0 + x1 * y1 + x2 * y2;
-      }
+    T gI[STRIP];
+    if constexpr (kSsim) {
+      // phase 2: forward statistics at every owned pixel q; publish 1/9 (g_mu_y, g_E[y^2], g_E[xy])(q)
+      WinSums<T> ws[STRIP];
+      V2 centre[STRIP];
+      strip_window_sums<T, STRIP>(sXY[c], strip * STRIP, col, ws, centre);
 #pragma unroll
       for (int k = 0; k < STRIP; ++k) {
-        const int ly = strip * STRIP + k;
-        const SsimStats<T> st = ssim_stats(hx_[k] + hx_[k + 1] + hx_[k + 2], hy_[k] + hy_[k + 1] + hy_[k + 2],
-                                           hxx[k] + hxx[k + 1] + hxx[k + 2], hyy[k] + hyy[k + 1] + hyy[k + 2],
-                                           hxy[k] + hxy[k + 1] + hxy[k + 2]);
-        bsum[k] += T(0.15) * l1v[k][c] + T(0.85) * clamp01(st.raw);
+        const SsimStats<T> st = ssim_stats(ws[k]);
+        bsum[k] += T(0.85) * clamp01(st.raw);
         // s = clamp((1 - S)/2, 0, 1): d s / d S = -1/2 inside the clamp (inclusive bounds)
         const T gS = (st.raw >= T(0) && st.raw <= T(1)) ? coef[k] * T(0.85) * T(-0.5) : T(0);
-        const T idd = T(1) / (st.d1 * st.d2);
-        const T ninth = T(1) / T(9);
-        T g1 = T(0), g2 = T(0), g3 = T(0);
-        if (gS != T(0)) {
-          g1 = gS * ((T(2) * st.mux * st.n2 - T(2) * st.mux * st.n1) * idd -
-                     st.S * (T(2) * st.muy / st.d1 - T(2) * st.muy / st.d2)) * ninth;  // d/d mu_y
-          g2 = -gS * st.S / st.d2 * ninth;                                              // d/d E[y^2]
-          g3 = gS * T(2) * st.n1 * idd * ninth;                                         // d/d E[xy]
-        }
+        T g1, g2, g3;
+        ssim_grad_y(st, gS, g1, g2, g3);
+        const int ly = strip * STRIP + k;
         sG[0][ly][col] = g1; sG[1][ly][col] = g2; sG[2][ly][col] = g3;
       }
       __syncthreads();
-      // phase 3: transpose of (reflect-pad + 3x3 box): 3x3 gather; an output on the image border
-      // is reached twice from its inner neighbour (pad[-1] = x[1])
+      // phase 3: transpose of (reflect-pad + 3x3 box) as a separable 3x3 gather
+      T gt[STRIP][3];
+      strip_box_transpose<T, STRIP, TH, 3>(sG, strip * STRIP, col, px, py0, H, W, gt);
 #pragma unroll
       for (int k = 0; k < STRIP; ++k) {
-        const int ly = strip * STRIP + k, py = oy + ly;
-        const bool mine = in_x && ly >= 1 && ly <= TH - 2 && inimg[k];
-        if (mine) {
-          T s1 = T(0), s2 = T(0), s3 = T(0);
-#pragma unroll
-          for (int dy = -1; dy <= 1; ++dy) {
-            const T wy = reflect_mult<T>(dy, py, H);
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-              const T w = reflect_mult<T>(dx, px, W) * wy;
-              s1 += w * sG[0][ly + dy][col + dx];
-              s2 += w * sG[1][ly + dy][col + dx];
-              s3 += w * sG[2][ly + dy][col + dx];
-            }
-          }
-          const T y = sIw[c][ly + 1][col + 1], x = sIt[c][ly + 1][col + 1];
-          const T gI = s1 + T(2) * y * s2 + x * s3 + coef[k] * T(0.15) * l1s[k][c];
-          gix[k] += gI * dIx[k][c];
-          giy[k] += gI * dIy[k][c];
-        }
+        const T x = centre[k][0], y = centre[k][1], d = x - y;
+        bsum[k] += T(0.15) * clamp01(t_abs(d));
+        // d clamp(|d|, 0, 1) / d Iw: the clamp passes gradient on [0, 1] inclusive, abs uses sgn
+        const T l1g = (t_abs(d) <= T(1)) ? -t_sgn(d) : T(0);
+        gI[k] = gt[k][0] + T(2) * y * gt[k][1] + x * gt[k][2] + coef[k] * T(0.15) * l1g;
       }
-      __syncthreads();
+      if (c < 2) __syncthreads();  // sG is rewritten by the next colour
     } else {
 #pragma unroll
       for (int k = 0; k < STRIP; ++k) {
-        bsum[k] += l1v[k][c];
-        const T gI = coef[k] * l1s[k][c];
-        gix[k] += gI * dIx[k][c];
-        giy[k] += gI * dIy[k][c];
+        const T d = cen[k][c][0] - cen[k][c][1];
+        bsum[k] += clamp01(t_abs(d));
+        gI[k] = coef[k] * ((t_abs(d) <= T(1)) ? -t_sgn(d) : T(0));
       }
     }
+#pragma unroll
+    for (int k = 0; k < STRIP; ++k) {
+      const int ly = strip * STRIP + k, py = py0 + k;
+      // note: m(p) = 0 still receives SSIM gradient through its neighbours' windows
+      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) gbuf[c * gplane + unsigned(py) * unsigned(W) + unsigned(px)] = gI[k];
+    }
   }
-  // ---- phase 4: depth-consistency term, scatter, geometry chain --------------------------------
+  // dL/d diff_depth: directly (geometry loss) and through the weight mask (no detach, loss_functions.py:111-113)
+#pragma unroll
+  for (int k = 0; k < STRIP; ++k) {
+    const int ly = strip * STRIP + k, py = py0 + k;
+    if (in_x && ly >= 1 && ly <= TH - 2 && py < H)
+      gbuf[3 * gplane + unsigned(py) * unsigned(W) + unsigned(px)] =
+          bg * mq[k] - (with_mask ? a * mq[k] * bsum[k] : T(0));
+  }
+}
+
+// ==========================================================================================
+// Backward, pass B (per pixel): through the bilinear sampler and the camera geometry.
+//   dL/d(ix, iy) = sum_c dL/dI_w,c * dI_w,c/d(ix, iy) + dL/dD_p * dD_p/d(ix, iy)
+//   dL/d ref_depth: atomic scatter of dL/dD_p over the taps; dL/d tgt_depth: dense accumulate;
+//   dL/d(A|c): block reduction, fp64 atomics per batch element.
+// ==========================================================================================
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
+    int H, int W, unsigned flags, const T* __restrict__ ref_img, const T* __restrict__ tgt_depth,
+    const T* __restrict__ ref_depth, const BatchConsts<T>* __restrict__ consts, const double* __restrict__ sums,
+    const T* __restrict__ g_photo, const T* __restrict__ g_geom, const T* __restrict__ gbuf,
+    T* __restrict__ g_tgt_depth, T* __restrict__ g_ref_depth, double* __restrict__ gP) {
+  constexpr int ROWS = 4;  // pixels per thread (amortises the 12-value block reduction)
+  __shared__ double red[12 * (kThreads / kWave)];
+  if (T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0)) return;  // as in pass A
+  const int b = blockIdx.z;
+  const int px = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const int py0 = (blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave) * ROWS;
+  const BatchConsts<T> bc = consts[b];
+  const unsigned plane = unsigned(H) * unsigned(W);
+  const size_t gplane = (size_t)gridDim.z * plane;
+  ref_img += (size_t)b * 3 * plane;
+  tgt_depth += (size_t)b * plane;
+  ref_depth += (size_t)b * plane;
+  g_tgt_depth += (size_t)b * plane;
+  g_ref_depth += (size_t)b * plane;
+  gbuf += (size_t)b * plane;
   T acc[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) acc[i] = T(0);
 #pragma unroll
-  for (int k = 0; k < STRIP; ++k) {
-    const int ly = strip * STRIP + k, py = oy + ly;
-    const bool mine = in_x && ly >= 1 && ly <= TH - 2 && inimg[k];
-    if (!mine) continue;  // note: m(p) = 0 still receives SSIM gradient through its neighbours' windows
-    const long p = (long)py * W + px;
+  for (int r = 0; r < ROWS; ++r) {
+    const int py = py0 + r;
+    if (px >= W || py >= H) continue;
+    const unsigned p = unsigned(py) * unsigned(W) + unsigned(px);
     const T d = tgt_depth[p];
+    const T gI0 = gbuf[p], gI1 = gbuf[gplane + p], gI2 = gbuf[2 * gplane + p], g_dd = gbuf[3 * gplane + p];
     const Sample<T> s = project_pixel(bc, px, py, d, H, W, flags);
+    const SampleGrad<T> sg = sample_grad(s);
     T t[4];
-    load_taps(ref_depth, s, W, t);
-    const T Dp = bilerp(t, s.fx, s.fy);
+    load_taps(ref_img, s, t);
+    T gix = gI0 * dot4(t, sg.cx), giy = gI0 * dot4(t, sg.cy);
+    load_taps(ref_img + plane, s, t);
+    gix += gI1 * dot4(t, sg.cx); giy += gI1 * dot4(t, sg.cy);
+    load_taps(ref_img + 2 * plane, s, t);
+    gix += gI2 * dot4(t, sg.cx); giy += gI2 * dot4(t, sg.cy);
+    load_taps(ref_depth, s, t);
+    const T Dp = bilerp(t, s);
     const T diff = s.Z - Dp, sum = s.Z + Dp;
-    const T raw = t_abs(diff) / sum;
-    // dL/d diff_depth: directly (geometry loss) and through the weight mask (no detach,
-    // loss_functions.py:111-113)
-    const T g_dd = bg * mq[k] - (with_mask ? a * mq[k] * bsum[k] : T(0));
+    const T isum = t_rcp(sum);
+    const T raw = t_abs(diff) * isum;
     T gZ = T(0), gDp = T(0);
-    if (raw >= T(0) && raw <= T(1)) {
-      const T sg = t_sgn(diff), i2 = T(1) / (sum * sum);
-      gZ = g_dd * (sg * T(2) * Dp * i2);
-      gDp = -g_dd * (sg * T(2) * s.Z * i2);
+    if (raw >= T(0) && raw <= T(1)) {  // diff_depth = clamp(|Z - Dp| / (Z + Dp), 0, 1), loss_functions.py:101
+      const T sgn = t_sgn(diff), i2 = isum * isum;
+      gZ = g_dd * (sgn * T(2) * Dp * i2);
+      gDp = -g_dd * (sgn * T(2) * s.Z * i2);
     }
-    const T gx_ = gix[k] + gDp * bilerp_dx(t, s.fx, s.fy);
-    const T gy_ = giy[k] + gDp * bilerp_dy(t, s.fx, s.fy);
-    scatter_taps(g_ref_depth, s, W, gDp);
-    g_tgt_depth[p] += pixel_geometry_bwd(bc, s, d, gx_, gy_, gZ, H, W, acc);
+    gix += gDp * dot4(t, sg.cx);
+    giy += gDp * dot4(t, sg.cy);
+    scatter_taps(g_ref_depth, s, gDp);
+    g_tgt_depth[p] += pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
   }
-  double accd[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) accd[i] = double(acc[i]);
-  block_sum<12>(accd, red);
+  block_sum<12>(acc, red);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < 12; ++i)
-      if (accd[i] != 0.0) atomicAdd(gP + 12 * b + i, accd[i]);
+      if (acc[i] != T(0)) atomicAdd(gP + 12 * b + i, double(acc[i]));
   }
 }
 
@@ -416,6 +395,7 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_kernel(
 template <typename T>
 static int pair_fwd(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth, const T* ref_depth,
                     const T* pose, const T* K, unsigned flags, void* ws, T* out, void* stream_) {
+  clear_status();
   if (B <= 0 || H < 2 || W < 2 || !tgt_img || !ref_img || !tgt_depth || !ref_depth || !pose || !K || !ws || !out)
     return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
@@ -433,15 +413,16 @@ static int pair_fwd(int B, int H, int W, const T* tgt_img, const T* ref_img, con
     hipLaunchKernelGGL((pair_fwd_kernel<T, false>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img, ref_img,
                        tgt_depth, ref_depth, (const BatchConsts<T>*)consts, partials);
   hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(1), dim3(kThreads), 0, stream, (int)(grid.x * grid.y * grid.z),
-                     (const double*)partials, sums, out);
-  return (int)hipGetLastError();
+                     (const double*)partials, sums, out, reinterpret_cast<double*>(base + l.off_gP), B * 12);
+  return launch_status();
 }
 
 template <typename T>
 static int pair_bwd(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth, const T* ref_depth,
-                    const T* pose, const T* K, unsigned flags, void* ws, const T* g_photo, const T* g_geom,
-                    T* g_tgt_depth, T* g_ref_depth, T* g_pose, void* stream_) {
-  if (B <= 0 || H < 2 || W < 2 || !tgt_img || !ref_img || !tgt_depth || !ref_depth || !pose || !K || !ws ||
+                    const T* pose, const T* K, unsigned flags, void* ws, void* scratch, const T* g_photo,
+                    const T* g_geom, T* g_tgt_depth, T* g_ref_depth, T* g_pose, void* stream_) {
+  clear_status();
+  if (B <= 0 || H < 2 || W < 2 || !tgt_img || !ref_img || !tgt_depth || !ref_depth || !pose || !K || !ws || !scratch ||
       !g_photo || !g_geom || !g_tgt_depth || !g_ref_depth || !g_pose)
     return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
@@ -450,32 +431,41 @@ static int pair_bwd(int B, int H, int W, const T* tgt_img, const T* ref_img, con
   auto* consts = reinterpret_cast<const BatchConsts<T>*>(base);
   const double* sums = reinterpret_cast<const double*>(base + l.off_sums);
   double* gP = reinterpret_cast<double*>(base + l.off_gP);
-  hipError_t e = hipMemsetAsync(gP, 0, (size_t)B * 12 * sizeof(double), stream);
-  if (e != hipSuccess) return (int)e;
+  T* gbuf = reinterpret_cast<T*>(scratch);
   dim3 grid(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), B);
-  if (flags & SCSFM_WITH_SSIM)
-    hipLaunchKernelGGL((pair_bwd_kernel<T, true>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img, ref_img,
-                       tgt_depth, ref_depth, consts, sums, g_photo, g_geom, g_tgt_depth, g_ref_depth, gP);
+  if (flags & SCSFM_DEBUG_SKIP_PHOTO) {
+  } else if (flags & SCSFM_WITH_SSIM)
+    hipLaunchKernelGGL((pair_bwd_photo_kernel<T, true>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img,
+                       ref_img, tgt_depth, ref_depth, consts, sums, g_photo, g_geom, gbuf);
   else
-    hipLaunchKernelGGL((pair_bwd_kernel<T, false>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img, ref_img,
-                       tgt_depth, ref_depth, consts, sums, g_photo, g_geom, g_tgt_depth, g_ref_depth, gP);
-  hipLaunchKernelGGL((pose_bwd_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, (const double*)gP,
-                     g_pose);
-  return (int)hipGetLastError();
+    hipLaunchKernelGGL((pair_bwd_photo_kernel<T, false>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img,
+                       ref_img, tgt_depth, ref_depth, consts, sums, g_photo, g_geom, gbuf);
+  dim3 grid_b(ceil_div(W, kWave), ceil_div(H, 4 * (kThreads / kWave)), B);
+  if (!(flags & SCSFM_DEBUG_SKIP_GEOM))
+    hipLaunchKernelGGL((pair_bwd_geom_kernel<T>), grid_b, dim3(kThreads), 0, stream, H, W, flags, ref_img, tgt_depth,
+                     ref_depth, consts, sums, g_photo, g_geom, (const T*)gbuf, g_tgt_depth, g_ref_depth, gP);
+  hipLaunchKernelGGL((pose_bwd_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, gP, g_pose);
+  return launch_status();
 }
 
 template <typename T>
 static int pair_refinalize(int B, int H, int W, void* ws, T* out, void* stream) {
+  clear_status();
   if (B <= 0 || H < 2 || W < 2 || !ws || !out) return SCSFM_ERR_ARG;
   const PairWs l = pair_ws_layout(B, H, W);
   double* sums = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + l.off_sums);
   hipLaunchKernelGGL((pair_refinalize_kernel<T>), dim3(1), dim3(kWave), 0, (hipStream_t)stream, sums, out);
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 }  // namespace scsfm
 
 extern "C" {
+
+size_t scsfm_pair_bwd_scratch_bytes(int B, int H, int W) {
+  if (B <= 0 || H < 2 || W < 2) return 0;
+  return (size_t)4 * B * H * W * sizeof(double);  // four planes; sized for fp64 so one buffer serves both
+}
 
 size_t scsfm_pair_ws_bytes(int B, int H, int W) {
   if (B <= 0 || H < 2 || W < 2) return 0;
@@ -493,10 +483,10 @@ size_t scsfm_pair_ws_bytes(int B, int H, int W) {
   }                                                                                                                   \
   int scsfm_pair_bwd_##SUF(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth,               \
                            const T* ref_depth, const T* pose, const T* K, unsigned flags, void* ws,                   \
-                           const T* g_photo, const T* g_geom, T* g_tgt_depth, T* g_ref_depth, T* g_pose,              \
-                           void* stream) {                                                                            \
-    return scsfm::pair_bwd<T>(B, H, W, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, ws, g_photo, g_geom,   \
-                              g_tgt_depth, g_ref_depth, g_pose, stream);                                              \
+                           void* scratch, const T* g_photo, const T* g_geom, T* g_tgt_depth, T* g_ref_depth,          \
+                           T* g_pose, void* stream) {                                                                 \
+    return scsfm::pair_bwd<T>(B, H, W, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, ws, scratch, g_photo,  \
+                              g_geom, g_tgt_depth, g_ref_depth, g_pose, stream);                                      \
   }
 
 int scsfm_pair_refinalize_f32(int B, int H, int W, void* ws, float* out, void* stream) {

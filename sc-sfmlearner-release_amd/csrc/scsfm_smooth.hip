@@ -56,38 +56,43 @@ __global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(int H, int W, cons
       if (y + 1 < H) sy += t_abs(d - depth[p + W]) * edge_weight(img, plane, p, p + W);
     }
   }
-  double v[3] = {double(sd), double(sx), double(sy)};
+  T v[3] = {sd, sx, sy};
   block_sum<3>(v, red);
   if (threadIdx.x == 0) {
     double* o = partials + 3 * ((long)(b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
-    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    o[0] = double(v[0]); o[1] = double(v[1]); o[2] = double(v[2]);
   }
 }
 
+// One block; each wave reduces whole images (b = wave, wave + 4, ...) with shuffles only, then the
+// per-wave loss contributions meet in LDS.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void smooth_finalize_kernel(int B, int H, int W, int nblk,
                                                                    const double* __restrict__ partials,
                                                                    double* __restrict__ per_img, T* __restrict__ out) {
-  __shared__ double red[3 * (kThreads / kWave)];
+  __shared__ double red[kThreads / kWave];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const double cnt_x = (double)B * H * (W - 1), cnt_y = (double)B * (H - 1) * W;
   double loss = 0.0;
-  for (int b = 0; b < B; ++b) {
-    double v[3] = {0, 0, 0};
-    for (int i = threadIdx.x; i < nblk; i += kThreads) {
-      const double* q = partials + 3 * ((long)b * nblk + i);
-      v[0] += q[0]; v[1] += q[1]; v[2] += q[2];
+  for (int b = wave; b < B; b += kThreads / kWave) {
+    double v0 = 0, v1 = 0, v2 = 0;
+    for (int i = lane; i < nblk; i += kWave) {
+      const double* q = partials + 3 * ((size_t)b * nblk + i);
+      v0 += q[0]; v1 += q[1]; v2 += q[2];
     }
-    block_sum<3>(v, red);
-    if (threadIdx.x == 0) {
-      const double den = v[0] / ((double)H * W) + 1e-7;
-      const double L = v[1] / cnt_x + v[2] / cnt_y;
-      per_img[2 * b] = den;
-      per_img[2 * b + 1] = L;
-      loss += L / den;
-    }
-    __syncthreads();
+    v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
+    const double den = v0 / ((double)H * W) + 1e-7;  // mean_HW(D) + 1e-7, loss_functions.py:139-140
+    const double L = v1 / cnt_x + v2 / cnt_y;
+    if (lane == 0) { per_img[2 * b] = den; per_img[2 * b + 1] = L; }
+    loss += L / den;
   }
-  if (threadIdx.x == 0) out[0] = T(loss);
+  if (lane == 0) red[wave] = loss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int w = 0; w < kThreads / kWave; ++w) t += red[w];
+    out[0] = T(t);
+  }
 }
 
 template <typename T>
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(int B, int H, int 
 
 template <typename T>
 static int smooth_fwd(int B, int H, int W, const T* depth, const T* img, void* ws, T* out, void* stream_) {
+  clear_status();
   if (B <= 0 || H < 2 || W < 2 || !depth || !img || !ws || !out) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const SmoothWs l = smooth_ws_layout(B, H, W);
@@ -133,19 +139,20 @@ static int smooth_fwd(int B, int H, int W, const T* depth, const T* img, void* w
                      partials);
   hipLaunchKernelGGL((smooth_finalize_kernel<T>), dim3(1), dim3(kThreads), 0, stream, B, H, W, l.nbx * l.nby,
                      (const double*)partials, per_img, out);
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 template <typename T>
 static int smooth_bwd(int B, int H, int W, const T* depth, const T* img, void* ws, const T* g_loss, T* g_depth,
                       void* stream_) {
+  clear_status();
   if (B <= 0 || H < 2 || W < 2 || !depth || !img || !ws || !g_loss || !g_depth) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const SmoothWs l = smooth_ws_layout(B, H, W);
   const double* per_img = reinterpret_cast<const double*>(reinterpret_cast<char*>(ws) + l.off_img);
   hipLaunchKernelGGL((smooth_bwd_kernel<T>), dim3(l.nbx, l.nby, B), dim3(kThreads), 0, stream, B, H, W, depth, img,
                      per_img, g_loss, g_depth);
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 }  // namespace scsfm

@@ -22,11 +22,11 @@ __global__ __launch_bounds__(kThreads) void warp_fwd_kernel(
   T t[4];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    load_taps(img + (b * 3 + c) * plane, s, W, t);
-    out_img[(b * 3 + c) * plane + p] = bilerp(t, s.fx, s.fy);
+    load_taps(img + (b * 3 + c) * plane, s, t);
+    out_img[(b * 3 + c) * plane + p] = bilerp(t, s);
   }
-  load_taps(ref_depth + b * plane, s, W, t);
-  out_pdepth[b * plane + p] = bilerp(t, s.fx, s.fy);
+  load_taps(ref_depth + b * plane, s, t);
+  out_pdepth[b * plane + p] = bilerp(t, s);
   out_valid[b * plane + p] = s.valid ? T(1) : T(0);
   out_cdepth[b * plane + p] = s.Z;
 }
@@ -49,33 +49,31 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(
   if (u < W && v < H) {
     const T d = depth[b * plane + p];
     const Sample<T> s = project_pixel(bc, u, v, d, H, W, flags);
+    const SampleGrad<T> sg = sample_grad(s);
     T gix = T(0), giy = T(0), t[4];
     if (g_img) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        load_taps(img + (b * 3 + c) * plane, s, W, t);
+        load_taps(img + (b * 3 + c) * plane, s, t);
         const T g = g_img[(b * 3 + c) * plane + p];
-        gix += g * bilerp_dx(t, s.fx, s.fy);
-        giy += g * bilerp_dy(t, s.fx, s.fy);
+        gix += g * dot4(t, sg.cx);
+        giy += g * dot4(t, sg.cy);
       }
     }
     if (g_pdepth) {
-      load_taps(ref_depth + b * plane, s, W, t);
+      load_taps(ref_depth + b * plane, s, t);
       const T g = g_pdepth[b * plane + p];
-      gix += g * bilerp_dx(t, s.fx, s.fy);
-      giy += g * bilerp_dy(t, s.fx, s.fy);
-      scatter_taps(g_ref_depth + b * plane, s, W, g);
+      gix += g * dot4(t, sg.cx);
+      giy += g * dot4(t, sg.cy);
+      scatter_taps(g_ref_depth + b * plane, s, g);
     }
     const T gZ = g_cdepth ? g_cdepth[b * plane + p] : T(0);
     g_depth[b * plane + p] += pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
   }
-  double accd[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) accd[i] = double(acc[i]);
-  block_sum<12>(accd, red);
+  block_sum<12>(acc, red);
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) atomicAdd(gP + 12 * b + i, accd[i]);
+    for (int i = 0; i < 12; ++i) atomicAdd(gP + 12 * b + i, double(acc[i]));
   }
 }
 
@@ -118,6 +116,7 @@ static inline size_t warp_ws_gP_offset(int B) { return (size_t)B * sizeof(BatchC
 template <typename T>
 static int warp_fwd(int B, int H, int W, const T* img, const T* depth, const T* ref_depth, const T* pose,
                     const T* K, unsigned flags, void* ws, T* o_img, T* o_valid, T* o_pd, T* o_cd, void* stream_) {
+  clear_status();
   if (B <= 0 || H < 2 || W < 2 || !img || !depth || !ref_depth || !pose || !K || !ws || !o_img || !o_valid ||
       !o_pd || !o_cd)
     return SCSFM_ERR_ARG;
@@ -127,13 +126,14 @@ static int warp_fwd(int B, int H, int W, const T* img, const T* depth, const T* 
   dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
   hipLaunchKernelGGL((warp_fwd_kernel<T>), grid, dim3(kThreads), 0, stream, H, W, flags,
                      img, depth, ref_depth, (const BatchConsts<T>*)consts, o_img, o_valid, o_pd, o_cd);
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 template <typename T>
 static int warp_bwd(int B, int H, int W, const T* img, const T* depth, const T* ref_depth, const T* pose,
                     const T* K, unsigned flags, void* ws, const T* g_img, const T* g_pd, const T* g_cd,
                     T* g_depth, T* g_ref_depth, T* g_pose, void* stream_) {
+  clear_status();
   if (B <= 0 || H < 2 || W < 2 || !img || !depth || !ref_depth || !pose || !K || !ws || !g_depth || !g_pose)
     return SCSFM_ERR_ARG;
   if (g_pd && !g_ref_depth) return SCSFM_ERR_ARG;
@@ -148,23 +148,25 @@ static int warp_bwd(int B, int H, int W, const T* img, const T* depth, const T* 
                      img, depth, ref_depth, (const BatchConsts<T>*)consts, g_img, g_pd, g_cd, g_depth, g_ref_depth,
                      gP);
   hipLaunchKernelGGL((pose_bwd_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K,
-                     (const double*)gP, g_pose);
-  return (int)hipGetLastError();
+                     gP, g_pose);
+  return launch_status();
 }
 
 template <typename T>
 static int pose_fwd(int B, const T* vec, int mode, T* mat, void* stream) {
+  clear_status();
   if (B <= 0 || !vec || !mat || (mode != SCSFM_ROT_EULER && mode != SCSFM_ROT_QUAT)) return SCSFM_ERR_ARG;
   hipLaunchKernelGGL((pose_mat_fwd_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, B, mode, vec,
                      mat);
-  return (int)hipGetLastError();
+  return launch_status();
 }
 template <typename T>
 static int pose_bwd(int B, const T* vec, int mode, const T* g_mat, T* g_vec, void* stream) {
+  clear_status();
   if (B <= 0 || !vec || !g_mat || !g_vec || (mode != SCSFM_ROT_EULER && mode != SCSFM_ROT_QUAT)) return SCSFM_ERR_ARG;
   hipLaunchKernelGGL((pose_mat_bwd_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, B, mode, vec,
                      g_mat, g_vec);
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 }  // namespace scsfm

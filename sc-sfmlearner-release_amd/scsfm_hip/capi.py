@@ -132,8 +132,14 @@ def pair_refinalize(lib, shape, ws, out):
     lib.call(f"scsfm_pair_refinalize_{_suffix(out)}", B, H, W, _p(ws), _p(out), _stream(out))
 
 
+def pair_bwd_scratch(lib, like, B, H, W):
+    """Device scratch of one pair backward (dL/d warped colours + dL/d diff_depth between its two
+    kernels); contents are irrelevant between calls, so consecutive calls on a stream may share it."""
+    return _ws(lib, "scsfm_pair_bwd_scratch_bytes", like, B, H, W)
+
+
 def pair_bwd(lib, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, ws, g_photo, g_geom,
-             g_tgt_depth=None, g_ref_depth=None):
+             g_tgt_depth=None, g_ref_depth=None, scratch=None):
     """Accumulates into g_tgt_depth / g_ref_depth (allocated zeroed when None); returns them and
     g_pose [B,6]."""
     _chk(tgt_img, ref_img, tgt_depth, ref_depth, pose, K, g_photo, g_geom, g_tgt_depth, g_ref_depth)
@@ -143,9 +149,11 @@ def pair_bwd(lib, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, ws, g_
     if g_ref_depth is None:
         g_ref_depth = torch.zeros_like(ref_depth)
     g_pose = torch.empty_like(pose)
+    if scratch is None:
+        scratch = pair_bwd_scratch(lib, tgt_img, B, H, W)
     lib.call(f"scsfm_pair_bwd_{_suffix(tgt_img)}", B, H, W, _p(tgt_img), _p(ref_img), _p(tgt_depth), _p(ref_depth),
-             _p(pose), _p(K), flags, _p(ws), _p(g_photo), _p(g_geom), _p(g_tgt_depth), _p(g_ref_depth), _p(g_pose),
-             _stream(tgt_img))
+             _p(pose), _p(K), flags, _p(ws), _p(scratch), _p(g_photo), _p(g_geom), _p(g_tgt_depth), _p(g_ref_depth),
+             _p(g_pose), _stream(tgt_img))
     return g_tgt_depth, g_ref_depth, g_pose
 
 
@@ -253,15 +261,17 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
     g_td = [torch.zeros_like(t) for t in tgt_depths]
     g_rd = [[torch.zeros_like(t) for t in r] for r in ref_depths]
     g_poses, g_poses_inv = [], []
+    B, _, H, W = tgt_img.shape
+    scratch = pair_bwd_scratch(lib, tgt_img, B, H, W)  # shared: the calls below are ordered on one stream
     j = 0
     for i in range(n_ref):
         gp_i = gpi_i = None
         for s in range(n_scales):
             dt, dr = tgt_depths[s], ref_depths[i][s]
             _, _, a = pair_bwd(lib, tgt_img, ref_imgs[i], dt, dr, poses[i], K, flags, wss[j], g_photo, g_geom,
-                               g_td[s], g_rd[i][s])
+                               g_td[s], g_rd[i][s], scratch)
             _, _, b = pair_bwd(lib, ref_imgs[i], tgt_img, dr, dt, poses_inv[i], K, flags, wss[j + 1], g_photo, g_geom,
-                               g_rd[i][s], g_td[s])
+                               g_rd[i][s], g_td[s], scratch)
             gp_i = a if gp_i is None else gp_i + a
             gpi_i = b if gpi_i is None else gpi_i + b
             j += 2

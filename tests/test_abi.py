@@ -10,7 +10,7 @@ from scsfm_hip import _lib
 
 EXPECTED = {
     "scsfm_abi_version",
-    "scsfm_pair_ws_bytes", "scsfm_pair_fwd_f32", "scsfm_pair_bwd_f32", "scsfm_pair_refinalize_f32",
+    "scsfm_pair_ws_bytes", "scsfm_pair_bwd_scratch_bytes", "scsfm_pair_fwd_f32", "scsfm_pair_bwd_f32", "scsfm_pair_refinalize_f32",
     "scsfm_pair_fwd_f64", "scsfm_pair_bwd_f64", "scsfm_pair_refinalize_f64",
     "scsfm_warp_ws_bytes", "scsfm_warp_fwd_f32", "scsfm_warp_bwd_f32", "scsfm_warp_fwd_f64", "scsfm_warp_bwd_f64",
     "scsfm_pose_vec2mat_fwd_f32", "scsfm_pose_vec2mat_bwd_f32", "scsfm_pose_vec2mat_fwd_f64",

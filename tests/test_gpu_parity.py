@@ -132,39 +132,52 @@ def test_pose_and_errors_goldens(LF, IW, dev):
 # ------------------------------------------------------------------------------------------------
 # 2. the CPU oracle on seeded inputs, up to BASELINE.json's full size
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,H,W,n_ref,dataset,depth", [
-    (2, 128, 416, 2, "kitti", "smooth"),
-    (3, 100, 210, 1, "kitti", "iid"),        # ragged: partial tiles
-    (12, 256, 832, 2, "kitti", "smooth"),    # configs[1] / [2] per-GPU workload
-    (4, 256, 320, 4, "nyu", "smooth"),       # configs[4]: NYU intrinsics, 4 refs
+@pytest.mark.parametrize("B,H,W,n_ref,dataset,depth,auto", [
+    (2, 128, 416, 2, "kitti", "smooth", 0),
+    (2, 128, 416, 2, "kitti", "smooth", 1),
+    (3, 100, 210, 1, "kitti", "iid", 1),        # ragged: partial tiles
+    (12, 256, 832, 2, "kitti", "smooth", 1),    # configs[1] / [2] per-GPU workload
+    (4, 256, 320, 4, "nyu", "smooth", 1),       # configs[4]: NYU intrinsics, 4 refs
 ])
-def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth):
+def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto):
+    """Losses to 1e-5 per pair term.  Gradients: the HIP fp32 result must be as close to the fp64
+    oracle as the fp32 oracle (= the reference's own arithmetic) is, up to a factor, plus 0.5 % of the
+    tensor's scale.  The factor matters for the pose gradients: with depths from 0.1 to 100 a handful
+    of near pixels carry most of d/d translation, so a single auto-mask decision that rounds the
+    other way (1-ulp difference) moves them by several per cent in ANY fp32
+    implementation, the reference included."""
     from oracle import scsfm_oracle as O
     from scsfm_hip import synth
     d = synth.make_batch(B, H, W, n_ref=n_ref, seed=17, depth=depth, image="smooth" if depth == "smooth" else "iid",
                          dataset=dataset)
-    flags = (1, 1, 1, "zeros")
+    flags = (1, 1, auto, "zeros")
 
-    def run(device, fn_pg, fn_s):
-        mv = lambda t: t.to(device).clone().requires_grad_(True)
+    def run(device, fn_pg, fn_s, dtype=torch.float32):
+        mv = lambda t: t.to(device=device, dtype=dtype).clone().requires_grad_(True)
+        cv = lambda t: t.to(device=device, dtype=dtype)
         td = [mv(t) for t in d["tgt_depth"]]
         rd = [[mv(t) for t in r] for r in d["ref_depths"]]
         ps, pi = [mv(p) for p in d["poses"]], [mv(p) for p in d["poses_inv"]]
-        tgt, refs, K = d["tgt_img"].to(device), [r.to(device) for r in d["ref_imgs"]], d["intrinsics"].to(device)
+        tgt, refs, K = cv(d["tgt_img"]), [cv(r) for r in d["ref_imgs"]], cv(d["intrinsics"])
         photo, geom = fn_pg(tgt, refs, K, td, rd, ps, pi, 1, *flags)
         smooth = fn_s(td, tgt, rd, refs)
         (photo + 0.1 * smooth + 0.5 * geom).backward()
         grads = [td[0].grad] + [r[0].grad for r in rd] + [p.grad for p in ps + pi]
-        return [float(photo), float(geom), float(smooth)], grads
+        return [float(photo.detach()), float(geom.detach()), float(smooth.detach())], [g.detach().cpu().double() for g in grads]
 
     vh, gh = run(dev, LF.compute_photo_and_geometry_loss, LF.compute_smooth_loss)
     vo, go = run("cpu", O.photo_and_geometry_loss, O.smooth_loss)
+    v64, g64 = run("cpu", O.photo_and_geometry_loss, O.smooth_loss, torch.float64)
     for a, b, nm in zip(vh, vo, ("photo", "geom", "smooth")):
         assert abs(a - b) <= 1e-5 * max(1, n_ref / 2), (nm, a, b)  # photo/geom are sums over 2*n_ref pair terms
-    for a, b in zip(gh[:1 + n_ref], go[:1 + n_ref]):
-        _scale_close(a, b.numpy(), rel=5e-3, bad=2e-3, what="depth grad")
-    for a, b in zip(gh[1 + n_ref:], go[1 + n_ref:]):
-        _scale_close(a, b.numpy(), rel=5e-3, bad=0.0, what="pose grad")
+    for i, (a, b, c) in enumerate(zip(gh, go, g64)):
+        scale = float(c.abs().max())
+        if i <= n_ref:   # depth maps: entry-wise with a small share of outliers (flipped pixels)
+            bad = ((a - b).abs() > 5e-3 * scale).double().mean().item()
+            assert bad <= 2e-3, (i, bad)
+        else:            # poses: every entry, noise-aware
+            ref_noise = (b - c).abs()
+            assert bool(((a - c).abs() <= 5e-3 * scale + 4 * ref_noise + 4 * ref_noise.max()).all()), (i, a, b, c)
 
 
 # ------------------------------------------------------------------------------------------------
