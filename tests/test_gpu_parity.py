@@ -17,6 +17,8 @@ from _util import assert_close_frac, load_inputs, load_npz
 
 pytestmark = pytest.mark.gpu
 
+# see test_hot_path_against_oracle: the reference's own fp32 pose gradients sit within ~1 % of fp64
+POSE_RTOL = 1.5e-2
 FLAGS = [(1, 1, 1), (1, 1, 0), (1, 0, 1), (1, 0, 0), (0, 1, 1), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
 
 
@@ -66,7 +68,7 @@ def test_pairwise_loss_goldens(LF, dev, name):
         assert abs(float(photo) - float(gold[f"{key}/photo"])) <= 1e-5, key
         assert abs(float(geom) - float(gold[f"{key}/geom"])) <= 1e-5, key
         (1.0 * photo + 0.5 * geom).backward()
-        _scale_close(po.grad, gold[f"{key}/g_pose"], what=key + " g_pose", bad=0.0) if name != "tiny" else None
+        _scale_close(po.grad, gold[f"{key}/g_pose"], rel=POSE_RTOL, what=key + " g_pose", bad=0.0) if name != "tiny" else None
         for nm, t in (("g_tgt_depth", td), ("g_ref_depth", rd)):
             st = gold[f"{key}/{nm}_stats"]
             assert abs(float(t.grad.double().abs().sum()) - st[1]) <= 2e-3 * st[1] + 1e-9, (key, nm)
@@ -95,8 +97,8 @@ def test_total_loss_goldens(LF, dev, name):
                 for i in range(2):
                     _scale_close(rd[i][s].grad, gold[f"{key}/g_ref{i}_depth_s{s}"], what=f"{key} ref{i} s{s}")
             for i in range(2):
-                _scale_close(ps[i].grad, gold[f"{key}/g_pose{i}"], bad=0.0)
-                _scale_close(pi[i].grad, gold[f"{key}/g_pose_inv{i}"], bad=0.0)
+                _scale_close(ps[i].grad, gold[f"{key}/g_pose{i}"], rel=POSE_RTOL, bad=0.0)
+                _scale_close(pi[i].grad, gold[f"{key}/g_pose_inv{i}"], rel=POSE_RTOL, bad=0.0)
 
 
 @pytest.mark.parametrize("name", ["smooth", "iid"])

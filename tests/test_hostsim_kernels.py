@@ -14,6 +14,10 @@ from oracle import scsfm_oracle as O
 from scsfm_hip import capi, synth
 from scsfm_hip._lib import ScsfmError
 
+# Pose gradients are sums dominated by a few near pixels (depth spans 0.1 .. 100), so one mask decision
+# that rounds the other way moves them by ~1 %: the reference's own fp32 result differs from its fp64
+# result by up to 1.2 % on such data (tests/test_gpu_parity.py measures this per case).
+POSE_RTOL = 1.5e-2
 FLAGS = [(1, 1, 1), (1, 1, 0), (1, 0, 1), (1, 0, 0), (0, 1, 1), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
 
 
@@ -93,7 +97,7 @@ def test_pair_fp32_matches_reference_goldens(lib, name):
         assert abs(float(out[1]) - float(gold[f"{key}/geom"])) <= 1e-5, key
         gt, gr, gp = capi.pair_bwd(lib, ti, ri, td, rd, po, K, fl, ws, w_photo, w_geom)
         g_pose = gold[f"{key}/g_pose"]
-        assert_close_frac(gp.numpy(), g_pose, atol=2e-3 * np.abs(g_pose).max() + 1e-7, what=key + " g_pose")
+        assert_close_frac(gp.numpy(), g_pose, atol=POSE_RTOL * np.abs(g_pose).max() + 1e-7, what=key + " g_pose")
         for nm, g in (("g_tgt_depth", gt), ("g_ref_depth", gr)):
             st = gold[f"{key}/{nm}_stats"]
             f = g.double().reshape(-1)
@@ -187,9 +191,9 @@ def test_total_loss_fp32_matches_reference_goldens(lib, name):
                 ref = gold[f"{key}/g_ref{i}_depth_s0"]
                 assert_close_frac((g_rd[i][0] + g_sm[1 + i]).numpy(), ref, atol=2e-3 * np.abs(ref).max(), rtol=1e-3,
                                   max_bad_frac=2e-3, what=f"{key} ref{i} s0")
-                assert_close_frac(g_p[i].numpy(), gold[f"{key}/g_pose{i}"], atol=2e-3 * np.abs(gold[f"{key}/g_pose{i}"]).max())
+                assert_close_frac(g_p[i].numpy(), gold[f"{key}/g_pose{i}"], atol=POSE_RTOL * np.abs(gold[f"{key}/g_pose{i}"]).max())
                 assert_close_frac(g_pi[i].numpy(), gold[f"{key}/g_pose_inv{i}"],
-                                  atol=2e-3 * np.abs(gold[f"{key}/g_pose_inv{i}"]).max())
+                                  atol=POSE_RTOL * np.abs(gold[f"{key}/g_pose_inv{i}"]).max())
             if n_scales == 2:
                 ref = gold[f"{key}/g_tgt_depth_s1"]
                 assert_close_frac(td[1].grad.numpy(), ref, atol=2e-3 * np.abs(ref).max(), rtol=1e-3, max_bad_frac=2e-3)
