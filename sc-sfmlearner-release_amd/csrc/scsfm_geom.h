@@ -136,6 +136,7 @@ struct Sample {
   unsigned off[4];  // element offset of each tap inside a plane, clamped into the image so that the
                     // four loads need no predication (their weight is 0 when they were clamped)
   unsigned inb;     // bit k: tap k lies inside the image
+  int x0, y0;       // north-west tap (unclamped)
   bool valid;       // max(|xn|, |yn|) <= 1   (inverse_warp.py:264)
 };
 
@@ -181,6 +182,7 @@ __device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int
   s.fx = ix - fx0;
   s.fy = iy - fy0;
   const int x0 = int(fx0), y0 = int(fy0), x1 = x0 + 1, y1 = y0 + 1;
+  s.x0 = x0; s.y0 = y0;
   const bool xw = x0 >= 0 && x0 < W, xe = x1 >= 0 && x1 < W;
   const bool yn_ = y0 >= 0 && y0 < H, ys = y1 >= 0 && y1 < H;
   s.inb = (xw && yn_ ? 1u : 0u) | (xe && yn_ ? 2u : 0u) | (xw && ys ? 4u : 0u) | (xe && ys ? 8u : 0u);
@@ -260,6 +262,39 @@ __device__ __forceinline__ void scatter_taps(T* __restrict__ gplane, const Sampl
   if (s.inb & 2u) atomicAdd(gplane + s.off[1], g * s.w[1]);
   if (s.inb & 4u) atomicAdd(gplane + s.off[2], g * s.w[2]);
   if (s.inb & 8u) atomicAdd(gplane + s.off[3], g * s.w[3]);
+}
+
+
+// The same scatter, staged through an LDS window that covers where a tile of neighbouring pixels
+// lands (motion is locally coherent): taps inside the window are LDS atomics, the rest fall back to
+// global atomics.  The window is flushed once per block with coalesced atomics (flush_scatter_window),
+// which cuts the device-scope atomic traffic from 4 per source pixel to ~1 per touched destination.
+constexpr int kWinW = 96, kWinH = 32;
+
+template <typename T>
+__device__ __forceinline__ void scatter_taps_window(T (*win)[kWinW], int wx0, int wy0, T* __restrict__ gplane,
+                                                    const Sample<T>& s, T g) {
+  if (g == T(0)) return;
+  const int lx = s.x0 - wx0, ly = s.y0 - wy0;
+  if (lx >= 0 && lx < kWinW - 1 && ly >= 0 && ly < kWinH - 1) {
+    if (s.inb & 1u) atomicAdd(&win[ly][lx], g * s.w[0]);
+    if (s.inb & 2u) atomicAdd(&win[ly][lx + 1], g * s.w[1]);
+    if (s.inb & 4u) atomicAdd(&win[ly + 1][lx], g * s.w[2]);
+    if (s.inb & 8u) atomicAdd(&win[ly + 1][lx + 1], g * s.w[3]);
+  } else {
+    scatter_taps(gplane, s, g);
+  }
+}
+
+// Only cells that received an in-image tap are non-zero, so every flushed cell is a valid pixel.
+template <typename T>
+__device__ __forceinline__ void flush_scatter_window(const T (*win)[kWinW], int wx0, int wy0, T* __restrict__ gplane,
+                                                     int W) {
+  for (int i = threadIdx.x; i < kWinW * kWinH; i += kThreads) {
+    const int ly = i / kWinW, lx = i - ly * kWinW;
+    const T v = win[ly][lx];
+    if (v != T(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), v);
+  }
 }
 
 }  // namespace scsfm

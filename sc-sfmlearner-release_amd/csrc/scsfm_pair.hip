@@ -331,8 +331,10 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
     const T* __restrict__ ref_depth, const BatchConsts<T>* __restrict__ consts, const double* __restrict__ sums,
     const T* __restrict__ g_photo, const T* __restrict__ g_geom, const T* __restrict__ gbuf,
     T* __restrict__ g_tgt_depth, T* __restrict__ g_ref_depth, double* __restrict__ gP) {
-  constexpr int ROWS = 4;  // pixels per thread (amortises the 12-value block reduction)
+  constexpr int ROWS = 4;  // pixels per thread: a block covers a 64 x 16 tile
   __shared__ double red[12 * (kThreads / kWave)];
+  __shared__ T win[kWinH][kWinW];  // staging window of the scatter into dL/d ref_depth
+  __shared__ int win_org[2];
   if (T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0)) return;  // as in pass A
   const int b = blockIdx.z;
   const int px = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
@@ -346,6 +348,16 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
   g_tgt_depth += (size_t)b * plane;
   g_ref_depth += (size_t)b * plane;
   gbuf += (size_t)b * plane;
+  // window origin: centred on where the tile's centre pixel lands in the reference view
+  for (int i = threadIdx.x; i < kWinW * kWinH; i += kThreads) (&win[0][0])[i] = T(0);
+  if (threadIdx.x == 2 * kWave + kWave / 2) {
+    const int cx = px < W ? px : W - 1, cy = py0 < H ? py0 : H - 1;
+    const Sample<T> sc = project_pixel(bc, cx, cy, tgt_depth[unsigned(cy) * unsigned(W) + unsigned(cx)], H, W, flags);
+    win_org[0] = sc.x0 - kWinW / 2;
+    win_org[1] = sc.y0 - kWinH / 2;
+  }
+  __syncthreads();
+  const int wx0 = win_org[0], wy0 = win_org[1];
   T acc[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) acc[i] = T(0);
@@ -378,9 +390,11 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
     }
     gix += gDp * dot4(t, sg.cx);
     giy += gDp * dot4(t, sg.cy);
-    scatter_taps(g_ref_depth, s, gDp);
+    scatter_taps_window(win, wx0, wy0, g_ref_depth, s, gDp);
     g_tgt_depth[p] += pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
   }
+  __syncthreads();
+  flush_scatter_window(win, wx0, wy0, g_ref_depth, W);
   block_sum<12>(acc, red);
   if (threadIdx.x == 0) {
 #pragma unroll

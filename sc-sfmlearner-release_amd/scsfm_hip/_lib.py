@@ -11,6 +11,13 @@ import os
 import re
 import threading
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so) while libscsfm_hip.so is linked
+# against the one under /opt/rocm.  Both carry the same SONAME, so whichever is loaded first serves
+# the whole process: importing torch first makes the kernels launch on the very runtime that owns
+# torch's streams and allocations.  (Loaded the other way round, the first launch fails with
+# hipErrorNoDevice.)
+import torch  # noqa: F401  (must precede ctypes.CDLL below)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "scsfm_hip.h")
 LIB_PATH = os.path.join(HERE, "libscsfm_hip.so")

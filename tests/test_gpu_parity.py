@@ -179,7 +179,7 @@ def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto):
             assert bad <= 2e-3, (i, bad)
         else:            # poses: every entry, noise-aware
             ref_noise = (b - c).abs()
-            assert bool(((a - c).abs() <= 5e-3 * scale + 4 * ref_noise + 4 * ref_noise.max()).all()), (i, a, b, c)
+            assert bool(((a - c).abs() <= POSE_RTOL * scale + 4 * ref_noise).all()), (i, a, b, c)
 
 
 # ------------------------------------------------------------------------------------------------
