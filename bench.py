@@ -107,6 +107,20 @@ def time_kernels(x, flags, iters):
         "pair_bwd": lambda: capi.pair_bwd(lib, *a, fl, ws, one, one, g_t, g_r, scratch),
         "pair_bwd_photo_only": lambda: capi.pair_bwd(lib, *a, fl | SKIP_GEOM, ws, one, one, g_t, g_r, scratch),
         "pair_bwd_geom_only": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO, ws, one, one, g_t, g_r, scratch),
+        "fwd_nossim": lambda: capi.pair_fwd_into(lib, *a, fl | 1024, out),
+        "fwd_noring": lambda: capi.pair_fwd_into(lib, *a, fl | 2048, out),
+        "fwd_nocolour": lambda: capi.pair_fwd_into(lib, *a, fl | 8192, out),
+        "fwd_none": lambda: capi.pair_fwd_into(lib, *a, fl | 1024 | 2048 | 8192, out),
+        "photo_nossim": lambda: capi.pair_bwd(lib, *a, fl | SKIP_GEOM | 1024, ws, one, one, g_t, g_r, scratch),
+        "photo_noring": lambda: capi.pair_bwd(lib, *a, fl | SKIP_GEOM | 2048, ws, one, one, g_t, g_r, scratch),
+        "photo_nocolour": lambda: capi.pair_bwd(lib, *a, fl | SKIP_GEOM | 8192, ws, one, one, g_t, g_r, scratch),
+        "photo_none": lambda: capi.pair_bwd(lib, *a, fl | SKIP_GEOM | 1024 | 2048 | 8192, ws, one, one, g_t, g_r, scratch),
+        "geom_noscatter": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | 1024, ws, one, one, g_t, g_r, scratch),
+        "geom_nodense": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | 2048, ws, one, one, g_t, g_r, scratch),
+        "geom_noreduce": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | 4096, ws, one, one, g_t, g_r, scratch),
+        "geom_nocolour": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | 8192, ws, one, one, g_t, g_r, scratch),
+        "geom_none": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | 1024 | 2048 | 4096 | 8192, ws, one, one, g_t, g_r, scratch),
+        "bwd_empty": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | SKIP_GEOM, ws, one, one, g_t, g_r, scratch),
         "smooth_fwd": lambda: capi.smooth_fwd(lib, dep, img, so),
         "smooth_bwd": lambda: capi.smooth_bwd(lib, dep, img, sws, one, g_t),
     }

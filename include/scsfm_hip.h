@@ -38,6 +38,12 @@ extern "C" {
 #define SCSFM_DEBUG_SKIP_PHOTO 256u /* scsfm_pair_bwd only, for per-kernel timing: skip the tiled pass */
 #define SCSFM_DEBUG_SKIP_GEOM 512u  /* scsfm_pair_bwd only, for per-kernel timing: skip the per-pixel pass */
 
+/* profiling only (results are WRONG): ablate one stage of the geometry pass */
+#define SCSFM_DEBUG_X1 1024u  /* no scatter into g_ref_depth (no LDS window, no atomics) */
+#define SCSFM_DEBUG_X2 2048u  /* no dense accumulate into g_tgt_depth */
+#define SCSFM_DEBUG_X3 4096u  /* no 12-value block reduction / gP atomics */
+#define SCSFM_DEBUG_X4 8192u  /* no colour-tap gathers */
+
 #define SCSFM_ROT_EULER 0 /* inverse_warp.py:77-112  */
 #define SCSFM_ROT_QUAT 1  /* inverse_warp.py:115-136 */
 
@@ -91,6 +97,38 @@ int scsfm_pair_bwd_f64(int B, int H, int W, const double* tgt_img, const double*
                        const double* intrinsics, unsigned flags, void* ws, void* scratch,
                        const double* g_photo, const double* g_geom, double* g_tgt_depth,
                        double* g_ref_depth, double* g_pose, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Several pair-directions per call -- what compute_photo_and_geometry_loss (loss_functions.py:56-90)
+ * needs per step: refs x scales x 2 directions.  `d` is a HOST array of n descriptors holding DEVICE
+ * pointers; every pair shares B, H, W, the intrinsics, the flags and (backward) the scratch buffer
+ * and the upstream gradients.  Field use: forward reads tgt_img..pose, ws, out; backward reads
+ * tgt_img..pose, ws and accumulates / stores g_tgt_depth, g_ref_depth, g_pose.  Semantics per pair
+ * are exactly those of scsfm_pair_fwd / scsfm_pair_bwd; the descriptors are consumed before return.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct scsfm_pair_desc {
+  const void* tgt_img;
+  const void* ref_img;
+  const void* tgt_depth;
+  const void* ref_depth;
+  const void* pose;
+  void* ws;
+  void* out;
+  void* g_tgt_depth;
+  void* g_ref_depth;
+  void* g_pose;
+} scsfm_pair_desc;
+
+int scsfm_pairs_fwd_f32(int n, const scsfm_pair_desc* d, int B, int H, int W, const float* intrinsics,
+                        unsigned flags, void* stream);
+int scsfm_pairs_bwd_f32(int n, const scsfm_pair_desc* d, int B, int H, int W, const float* intrinsics,
+                        unsigned flags, void* scratch, const float* g_photo, const float* g_geom,
+                        void* stream);
+int scsfm_pairs_fwd_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, const double* intrinsics,
+                        unsigned flags, void* stream);
+int scsfm_pairs_bwd_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, const double* intrinsics,
+                        unsigned flags, void* scratch, const double* g_photo, const double* g_geom,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * inverse_warp2 (inverse_warp.py:230-269) as maps: projected_img [B,3,H,W], valid_mask [B,1,H,W]
@@ -173,6 +211,20 @@ int scsfm_masked_mean_fwd_f64(int B, int C, int Cm, int HW, const double* diff, 
                               void* ws, double* out, void* stream);
 int scsfm_masked_mean_bwd_f64(int B, int C, int Cm, int HW, const double* mask, void* ws,
                               const double* g, double* g_diff, void* stream);
+
+/* compute_smooth_loss (loss_functions.py:154-159): n frames per call.  depths / imgs / g_depths are
+ * HOST arrays of n DEVICE pointers; ws = n * scsfm_smooth_ws_bytes(B,H,W) bytes; out[n] (device,
+ * store) holds one loss per frame; a NULL g_depths[i] skips that frame's gradient. */
+int scsfm_smooth_multi_fwd_f32(int n, const void* const* depths, const void* const* imgs, int B, int H,
+                               int W, void* ws, float* out, void* stream);
+int scsfm_smooth_multi_bwd_f32(int n, const void* const* depths, const void* const* imgs, int B, int H,
+                               int W, void* ws, const float* g_loss, void* const* g_depths,
+                               void* stream);
+int scsfm_smooth_multi_fwd_f64(int n, const void* const* depths, const void* const* imgs, int B, int H,
+                               int W, void* ws, double* out, void* stream);
+int scsfm_smooth_multi_bwd_f64(int n, const void* const* depths, const void* const* imgs, int B, int H,
+                               int W, void* ws, const double* g_loss, void* const* g_depths,
+                               void* stream);
 
 #ifdef __cplusplus
 }

@@ -41,7 +41,9 @@ struct BatchConsts {
 // Workspace layout of one pair-direction call (scsfm_pair_ws_bytes).
 //   [0]                consts   : B x BatchConsts<double>-sized slots (T = float uses the front)
 //   [off_sums]         sums     : double[8] = {S_photo, S_geom, S_m, photo, geom, a, b, -}
-//   [off_gP]           gP       : double[B][12]   (gradient of A|c, accumulated with fp64 atomics)
+//   [off_gP]           gPp      : double[B][geom blocks per image][12]  (per-block partial gradients of A|c;
+//                                 reduced by pose_reduce_bwd_kernel -- same-address atomics from ~200 blocks per
+//                                 image cost 60 us per launch, partials cost nothing)
 //   [off_partials]     partials : double[nblocks][3]
 struct PairWs {
   size_t off_sums, off_gP, off_partials, total;
@@ -62,7 +64,7 @@ inline PairWs pair_ws_layout(int B, int H, int W) {
   l.nby = ceil_div(H, kTileH);
   size_t off = (size_t)B * sizeof(BatchConsts<double>);
   l.off_sums = off; off += 8 * sizeof(double);
-  l.off_gP = off; off += (size_t)B * 12 * sizeof(double);
+  l.off_gP = off; off += (size_t)B * ceil_div(W, kWave) * ceil_div(H, 16) * 12 * sizeof(double);
   l.off_partials = off; off += (size_t)l.nbx * l.nby * B * 3 * sizeof(double);
   l.total = (off + 255) & ~(size_t)255;
   return l;

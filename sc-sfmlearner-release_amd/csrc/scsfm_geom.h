@@ -97,16 +97,10 @@ __global__ void prep_kernel(int B, const T* __restrict__ pose, const T* __restri
   out[b] = o;
 }
 
-// gP = dL/d(A|c) [B][12] (fp64 accumulators) -> dL/dpose [B,6]:  gT = K^T gP, then the euler chain.
+// dL/d(A|c) (12 numbers, fp64) of one batch element -> dL/dpose: gT = K^T gP, then the euler chain.
 template <typename T>
-__global__ void pose_bwd_kernel(int B, const T* __restrict__ pose, const T* __restrict__ K,
-                                double* __restrict__ gP, T* __restrict__ gpose) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const T* k = K + 9 * b;
-  double g[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) { g[i] = gP[12 * b + i]; gP[12 * b + i] = 0.0; }  // consumed: ready for the next backward
+__device__ __forceinline__ void pose_from_gP(const T* __restrict__ k, const T* __restrict__ p, const double* g,
+                                             T* __restrict__ o) {
   T gR[9], gt[3];
 #pragma unroll
   for (int kk = 0; kk < 3; ++kk) {
@@ -115,12 +109,47 @@ __global__ void pose_bwd_kernel(int B, const T* __restrict__ pose, const T* __re
       gR[3 * kk + j] = T(double(k[kk]) * g[j] + double(k[3 + kk]) * g[3 + j] + double(k[6 + kk]) * g[6 + j]);
     gt[kk] = T(double(k[kk]) * g[9] + double(k[3 + kk]) * g[10] + double(k[6 + kk]) * g[11]);
   }
-  const T* p = pose + 6 * b;
   T ga[3];
   euler_bwd(p[3], p[4], p[5], gR, ga);
-  T* o = gpose + 6 * b;
   o[0] = gt[0]; o[1] = gt[1]; o[2] = gt[2];
   o[3] = ga[0]; o[4] = ga[1]; o[5] = ga[2];
+}
+
+// gP [B][12] accumulated with atomics (warp_bwd path); re-zeroed after use.
+template <typename T>
+__global__ void pose_bwd_kernel(int B, const T* __restrict__ pose, const T* __restrict__ K,
+                                double* __restrict__ gP, T* __restrict__ gpose) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double g[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { g[i] = gP[12 * b + i]; gP[12 * b + i] = 0.0; }  // consumed: ready for the next backward
+  pose_from_gP(K + 9 * b, pose + 6 * b, g, gpose + 6 * b);
+}
+
+// One wave per batch element: ordered fp64 reduction of the per-block partials gPp[b][nblk][12]
+// written by pair_bwd_geom_kernel, then the pose chain.  `live` = the geometry pass ran (it skips
+// when both upstream coefficients are zero and then leaves the partials untouched).
+template <typename T>
+__global__ void pose_reduce_bwd_kernel(int nblk, const T* __restrict__ pose, const T* __restrict__ K,
+                                       const double* __restrict__ gPp, const double* __restrict__ sums,
+                                       const T* __restrict__ g_photo, const T* __restrict__ g_geom,
+                                       T* __restrict__ gpose) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const bool live = !(T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0));
+  double g[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) g[i] = 0.0;
+  if (live) {
+    for (int j = lane; j < nblk; j += kWave) {
+      const double* q = gPp + ((size_t)b * nblk + j) * 12;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) g[i] += q[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) g[i] = wave_sum(g[i]);
+  }
+  if (lane == 0) pose_from_gP(K + 9 * b, pose + 6 * b, g, gpose + 6 * b);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -31,6 +31,7 @@ __device__ __forceinline__ Sample<T> warp_colours(const BatchConsts<T>& bc, int 
   T t[4];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
+    if (flags & SCSFM_DEBUG_X4) { xy[c] = make2(tgt_img[c * plane + p], T(0)); continue; }  // profiling only
     load_taps(ref_img + c * plane, s, t);
     xy[c] = make2(tgt_img[c * plane + p], bilerp(t, s));
   }
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(
   }
   // ---- phase 1b: the 1-pixel ring (SSIM windows of the tile's border pixels) ------------------
   if (kSsim) {
-    if (threadIdx.x < 2 * kHaloW + 2 * TH) {
+    if (threadIdx.x < 2 * kHaloW + 2 * TH && !(flags & SCSFM_DEBUG_X2)) {
       int hy, hx;
       ring_pos<TH>(threadIdx.x, hy, hx);
       const int u = reflect_index(tx0 + hx - 1, W), v = reflect_index(ty0 + hy - 1, H);
@@ -116,13 +117,15 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(
 #pragma unroll
   for (int k = 0; k < STRIP; ++k) photo[k] = kSsim ? T(0.15) * l1sum[k] : l1sum[k];  // loss_functions.py:109
   if constexpr (kSsim) {
+    if (!(flags & SCSFM_DEBUG_X1)) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      WinSums<T> ws[STRIP];
-      V2 centre[STRIP];
-      strip_window_sums<T, STRIP>(sXY[c], strip * STRIP, col, ws, centre);
+      for (int c = 0; c < 3; ++c) {
+        WinSums<T> ws[STRIP];
+        V2 centre[STRIP];
+        strip_window_sums<T, STRIP>(sXY[c], strip * STRIP, col, ws, centre);
 #pragma unroll
-      for (int k = 0; k < STRIP; ++k) photo[k] += T(0.85) * clamp01(ssim_stats(ws[k]).raw);
+        for (int k = 0; k < STRIP; ++k) photo[k] += T(0.85) * clamp01(ssim_stats(ws[k]).raw);
+      }
     }
   }
   T acc_p = T(0), acc_g = T(0), acc_m = T(0);
@@ -162,11 +165,8 @@ __device__ __forceinline__ void publish_losses(double Sp, double Sg, double Sm, 
 // the coefficients the backward multiplies the upstream gradients with.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(int nblocks, const double* __restrict__ partials,
-                                                                 double* __restrict__ sums, T* __restrict__ out,
-                                                                 double* __restrict__ gP, int n_gP) {
+                                                                 double* __restrict__ sums, T* __restrict__ out) {
   __shared__ double red[3 * (kThreads / kWave)];
-  // the backward accumulates dL/d(A|c) here with atomics; pose_bwd_kernel re-zeroes it after use
-  for (int i = threadIdx.x; i < n_gP; i += kThreads) gP[i] = 0.0;
   double v[3] = {0, 0, 0};
   for (int i = threadIdx.x; i < nblocks; i += kThreads) {
     v[0] += partials[3 * i]; v[1] += partials[3 * i + 1]; v[2] += partials[3 * i + 2];
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
   }
   // ---- phase 1b: ring ------------------------------------------------------------------------
   if constexpr (kSsim) {
-    if (threadIdx.x < 2 * kHaloW + 2 * TH) {
+    if (threadIdx.x < 2 * kHaloW + 2 * TH && !(flags & SCSFM_DEBUG_X2)) {
       int hy, hx;
       ring_pos<TH>(threadIdx.x, hy, hx);
       const int u = reflect_index(ox + hx - 1, W), v = reflect_index(oy + hy - 1, H);
@@ -265,7 +265,10 @@ __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     T gI[STRIP];
-    if constexpr (kSsim) {
+    if (flags & SCSFM_DEBUG_X1) {  // profiling only
+#pragma unroll
+      for (int k = 0; k < STRIP; ++k) gI[k] = coef[k];
+    } else if constexpr (kSsim) {
       // phase 2: forward statistics at every owned pixel q; publish 1/9 (g_mu_y, g_E[y^2], g_E[xy])(q)
       WinSums<T> ws[STRIP];
       V2 centre[STRIP];
@@ -371,12 +374,15 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
     const Sample<T> s = project_pixel(bc, px, py, d, H, W, flags);
     const SampleGrad<T> sg = sample_grad(s);
     T t[4];
-    load_taps(ref_img, s, t);
-    T gix = gI0 * dot4(t, sg.cx), giy = gI0 * dot4(t, sg.cy);
-    load_taps(ref_img + plane, s, t);
-    gix += gI1 * dot4(t, sg.cx); giy += gI1 * dot4(t, sg.cy);
-    load_taps(ref_img + 2 * plane, s, t);
-    gix += gI2 * dot4(t, sg.cx); giy += gI2 * dot4(t, sg.cy);
+    T gix = T(0), giy = T(0);
+    if (!(flags & SCSFM_DEBUG_X4)) {
+      load_taps(ref_img, s, t);
+      gix = gI0 * dot4(t, sg.cx); giy = gI0 * dot4(t, sg.cy);
+      load_taps(ref_img + plane, s, t);
+      gix += gI1 * dot4(t, sg.cx); giy += gI1 * dot4(t, sg.cy);
+      load_taps(ref_img + 2 * plane, s, t);
+      gix += gI2 * dot4(t, sg.cx); giy += gI2 * dot4(t, sg.cy);
+    }
     load_taps(ref_depth, s, t);
     const T Dp = bilerp(t, s);
     const T diff = s.Z - Dp, sum = s.Z + Dp;
@@ -390,16 +396,22 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
     }
     gix += gDp * dot4(t, sg.cx);
     giy += gDp * dot4(t, sg.cy);
-    scatter_taps_window(win, wx0, wy0, g_ref_depth, s, gDp);
-    g_tgt_depth[p] += pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
+    if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window(win, wx0, wy0, g_ref_depth, s, gDp);
+    const T gd = pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
+    if (!(flags & SCSFM_DEBUG_X2)) g_tgt_depth[p] += gd; else if (gd == T(12345)) g_tgt_depth[p] = gd;
   }
   __syncthreads();
-  flush_scatter_window(win, wx0, wy0, g_ref_depth, W);
+  if (!(flags & SCSFM_DEBUG_X1)) flush_scatter_window(win, wx0, wy0, g_ref_depth, W);
+  if (flags & SCSFM_DEBUG_X3) {  // profiling: keep the partials defined
+    if (threadIdx.x == 0)
+      for (int i = 0; i < 12; ++i) gP[12 * ((size_t)(b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) + i] = 0.0;
+    return;
+  }
   block_sum<12>(acc, red);
   if (threadIdx.x == 0) {
+    double* o = gP + 12 * ((size_t)(b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 #pragma unroll
-    for (int i = 0; i < 12; ++i)
-      if (acc[i] != T(0)) atomicAdd(gP + 12 * b + i, double(acc[i]));
+    for (int i = 0; i < 12; ++i) o[i] = double(acc[i]);
   }
 }
 
@@ -427,7 +439,7 @@ static int pair_fwd(int B, int H, int W, const T* tgt_img, const T* ref_img, con
     hipLaunchKernelGGL((pair_fwd_kernel<T, false>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img, ref_img,
                        tgt_depth, ref_depth, (const BatchConsts<T>*)consts, partials);
   hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(1), dim3(kThreads), 0, stream, (int)(grid.x * grid.y * grid.z),
-                     (const double*)partials, sums, out, reinterpret_cast<double*>(base + l.off_gP), B * 12);
+                     (const double*)partials, sums, out);
   return launch_status();
 }
 
@@ -458,7 +470,8 @@ static int pair_bwd(int B, int H, int W, const T* tgt_img, const T* ref_img, con
   if (!(flags & SCSFM_DEBUG_SKIP_GEOM))
     hipLaunchKernelGGL((pair_bwd_geom_kernel<T>), grid_b, dim3(kThreads), 0, stream, H, W, flags, ref_img, tgt_depth,
                      ref_depth, consts, sums, g_photo, g_geom, (const T*)gbuf, g_tgt_depth, g_ref_depth, gP);
-  hipLaunchKernelGGL((pose_bwd_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, gP, g_pose);
+  hipLaunchKernelGGL((pose_reduce_bwd_kernel<T>), dim3(B), dim3(kWave), 0, stream, (int)(grid_b.x * grid_b.y), pose, K,
+                     (const double*)gP, sums, g_photo, g_geom, g_pose);
   return launch_status();
 }
 
@@ -488,6 +501,35 @@ size_t scsfm_pair_ws_bytes(int B, int H, int W) {
   size_t nb = (size_t)scsfm::ceil_div(W, scsfm::kTileW) * scsfm::ceil_div(H, scsfm::Tile<double>::kH) * B;
   return (l.off_partials + nb * 3 * sizeof(double) + 255) & ~(size_t)255;
 }
+
+// Several pair-directions per call: one trip through the binding layer per step instead of one per
+// pair (the per-call host cost of a ctypes round trip, ~25 us, is comparable to a kernel here).
+#define SCSFM_PAIRS_API(SUF, T)                                                                                       \
+  int scsfm_pairs_fwd_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,          \
+                            void* stream) {                                                                           \
+    if (n < 0 || (n > 0 && !d)) return SCSFM_ERR_ARG;                                                                 \
+    for (int i = 0; i < n; ++i) {                                                                                     \
+      int rc = scsfm::pair_fwd<T>(B, H, W, (const T*)d[i].tgt_img, (const T*)d[i].ref_img, (const T*)d[i].tgt_depth,  \
+                                  (const T*)d[i].ref_depth, (const T*)d[i].pose, K, flags, d[i].ws, (T*)d[i].out,     \
+                                  stream);                                                                            \
+      if (rc) return rc;                                                                                              \
+    }                                                                                                                 \
+    return SCSFM_OK;                                                                                                  \
+  }                                                                                                                   \
+  int scsfm_pairs_bwd_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,          \
+                            void* scratch, const T* g_photo, const T* g_geom, void* stream) {                         \
+    if (n < 0 || (n > 0 && !d)) return SCSFM_ERR_ARG;                                                                 \
+    for (int i = 0; i < n; ++i) {                                                                                     \
+      int rc = scsfm::pair_bwd<T>(B, H, W, (const T*)d[i].tgt_img, (const T*)d[i].ref_img, (const T*)d[i].tgt_depth,  \
+                                  (const T*)d[i].ref_depth, (const T*)d[i].pose, K, flags, d[i].ws, scratch, g_photo, \
+                                  g_geom, (T*)d[i].g_tgt_depth, (T*)d[i].g_ref_depth, (T*)d[i].g_pose, stream);       \
+      if (rc) return rc;                                                                                              \
+    }                                                                                                                 \
+    return SCSFM_OK;                                                                                                  \
+  }
+
+SCSFM_PAIRS_API(f32, float)
+SCSFM_PAIRS_API(f64, double)
 
 #define SCSFM_PAIR_API(SUF, T)                                                                                        \
   int scsfm_pair_fwd_##SUF(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth,               \

@@ -173,6 +173,34 @@ size_t scsfm_smooth_ws_bytes(int B, int H, int W) {
     return scsfm::smooth_bwd<T>(B, H, W, depth, img, ws, g_loss, g_depth, stream);                                   \
   }
 
+#define SCSFM_SMOOTH_MULTI_API(SUF, T)                                                                               \
+  int scsfm_smooth_multi_fwd_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,   \
+                                   void* ws, T* out, void* stream) {                                                 \
+    if (n < 0 || (n > 0 && (!depths || !imgs || !ws || !out))) return SCSFM_ERR_ARG;                                 \
+    const size_t stride = scsfm::smooth_ws_layout(B, H, W).total;                                                    \
+    for (int i = 0; i < n; ++i) {                                                                                    \
+      int rc = scsfm::smooth_fwd<T>(B, H, W, (const T*)depths[i], (const T*)imgs[i], (char*)ws + i * stride,         \
+                                    out + i, stream);                                                                \
+      if (rc) return rc;                                                                                             \
+    }                                                                                                                \
+    return SCSFM_OK;                                                                                                 \
+  }                                                                                                                  \
+  int scsfm_smooth_multi_bwd_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,   \
+                                   void* ws, const T* g_loss, void* const* g_depths, void* stream) {                 \
+    if (n < 0 || (n > 0 && (!depths || !imgs || !ws || !g_loss || !g_depths))) return SCSFM_ERR_ARG;                 \
+    const size_t stride = scsfm::smooth_ws_layout(B, H, W).total;                                                    \
+    for (int i = 0; i < n; ++i) {                                                                                    \
+      if (!g_depths[i]) continue;                                                                                    \
+      int rc = scsfm::smooth_bwd<T>(B, H, W, (const T*)depths[i], (const T*)imgs[i], (char*)ws + i * stride, g_loss, \
+                                    (T*)g_depths[i], stream);                                                        \
+      if (rc) return rc;                                                                                             \
+    }                                                                                                                \
+    return SCSFM_OK;                                                                                                 \
+  }
+
+SCSFM_SMOOTH_MULTI_API(f32, float)
+SCSFM_SMOOTH_MULTI_API(f64, double)
+
 SCSFM_SMOOTH_API(f32, float)
 SCSFM_SMOOTH_API(f64, double)
 

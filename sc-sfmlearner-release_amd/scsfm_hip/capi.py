@@ -222,66 +222,141 @@ def masked_mean_bwd(lib, diff_shape, mask, ws, g):
 
 
 # -- compute_photo_and_geometry_loss: refs x scales x both directions ----------------------------
+import ctypes as _ct
+import functools as _ft
+
+
+class PairDesc(_ct.Structure):
+    """scsfm_pair_desc of include/scsfm_hip.h."""
+    _fields_ = [(n, _ct.c_void_p) for n in ("tgt_img", "ref_img", "tgt_depth", "ref_depth", "pose", "ws", "out",
+                                            "g_tgt_depth", "g_ref_depth", "g_pose")]
+
+
+@_ft.lru_cache(maxsize=64)
+def _sizes(lib, B, H, W):
+    return (lib.size("scsfm_pair_ws_bytes", B, H, W), lib.size("scsfm_pair_bwd_scratch_bytes", B, H, W),
+            lib.size("scsfm_smooth_ws_bytes", B, H, W))
+
+
+def _pair_list(tgt_img, ref_imgs, tgt_depths, ref_depths, poses, poses_inv):
+    """(tgt_img, ref_img, tgt_depth, ref_depth, pose, key_tgt, key_ref) per pair-direction, in the
+    reference's order: for each ref, for each scale: tgt -> ref (loss_functions.py:84), ref -> tgt (:86)."""
+    pairs = []
+    for i, ref in enumerate(ref_imgs):
+        for s, dt in enumerate(tgt_depths):
+            dr = ref_depths[i][s]
+            pairs.append((tgt_img, ref, dt, dr, poses[i], ("t", s), ("r", i, s)))
+            pairs.append((ref, tgt_img, dr, dt, poses_inv[i], ("r", i, s), ("t", s)))
+    return pairs
+
+
 def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, group=None):
-    """All pair-directions of loss_functions.py:56-90.  ``tgt_depths[s]`` and
-    ``ref_depths[i][s]`` are full-resolution maps.  Returns (photo, geom, outs [n_pairs, 8], wss).
+    """All pair-directions of loss_functions.py:56-90 in ONE call into the library.  ``tgt_depths[s]``
+    and ``ref_depths[i][s]`` are full-resolution maps.  Returns (photo, geom, outs [n_pairs, 8], ws)
+    where ``ws`` (one tensor, n_pairs slices) must reach photo_geometry_bwd untouched.
 
     ``group``: a torch.distributed process group -> exact data-parallel mode: the three raw sums of
     every pair are all-reduced (one [n_pairs, 3] collective) and the masked means are re-evaluated on
-    the global sums, so every rank holds the losses of the concatenated batch (SURVEY.md §8e)."""
-    n_ref, n_scales = len(ref_imgs), len(tgt_depths)
-    outs = torch.empty(2 * n_ref * n_scales, 8, dtype=tgt_img.dtype, device=tgt_img.device)
-    wss = []
-    j = 0
-    for i in range(n_ref):
-        for s in range(n_scales):
-            dt, dr = tgt_depths[s], ref_depths[i][s]
-            # direction tgt -> ref (loss_functions.py:84) then ref -> tgt (:86)
-            wss.append(pair_fwd_into(lib, tgt_img, ref_imgs[i], dt, dr, poses[i], K, flags, outs[j]))
-            wss.append(pair_fwd_into(lib, ref_imgs[i], tgt_img, dr, dt, poses_inv[i], K, flags, outs[j + 1]))
-            j += 2
+    the global sums, so every rank holds the losses of the concatenated batch (SURVEY.md 8e)."""
+    B, _, H, W = tgt_img.shape
+    pairs = _pair_list(tgt_img, ref_imgs, tgt_depths, ref_depths, poses, poses_inv)
+    n = len(pairs)
+    every = [tgt_img, K] + list(ref_imgs) + list(tgt_depths) + [d for r in ref_depths for d in r] + list(poses) + \
+        list(poses_inv)
+    _chk(*every)
+    check_sizes(K, "intrinsics", (B, 3, 3))
+    for r in ref_imgs:
+        check_sizes(r, "ref_img", (B, 3, H, W))
+    for d in list(tgt_depths) + [d for r in ref_depths for d in r]:
+        check_sizes(d, "depth", (B, 1, H, W))
+    for p in list(poses) + list(poses_inv):
+        check_sizes(p, "pose", (B, 6))
+    ws_bytes = _sizes(lib, B, H, W)[0]
+    ws = torch.empty(n * ws_bytes, dtype=torch.uint8, device=tgt_img.device)
+    outs = torch.empty(n, 8, dtype=tgt_img.dtype, device=tgt_img.device)
+    descs = (PairDesc * n)()
+    wp, op, esz = ws.data_ptr(), outs.data_ptr(), outs.element_size() * 8
+    for j, (ti, ri, dt, dr, po, _, _) in enumerate(pairs):
+        d = descs[j]
+        d.tgt_img, d.ref_img, d.tgt_depth, d.ref_depth, d.pose = ti.data_ptr(), ri.data_ptr(), dt.data_ptr(), \
+            dr.data_ptr(), po.data_ptr()
+        d.ws, d.out = wp + j * ws_bytes, op + j * esz
+    lib.call(f"scsfm_pairs_fwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags, _stream(tgt_img))
     if group is not None:
         import torch.distributed as dist
         sums = outs[:, 2:5].contiguous()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
         outs[:, 2:5] = sums
-        B, _, H, W = tgt_img.shape
-        for j, ws in enumerate(wss):
-            pair_refinalize(lib, (B, H, W), ws, outs[j])
+        for j in range(n):
+            pair_refinalize(lib, (B, H, W), ws[j * ws_bytes:(j + 1) * ws_bytes], outs[j])
     tot = outs[:, :2].sum(dim=0)  # plain sums over refs, scales and directions (loss_functions.py:89-90)
-    return tot[0], tot[1], outs, wss
+    return tot[0], tot[1], outs, ws
 
 
-def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, wss, g_photo,
+def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws, g_photo,
                        g_geom):
     """Gradients of photo_geometry_fwd's two sums: (g_tgt_depths[s], g_ref_depths[i][s], g_poses[i],
     g_poses_inv[i]).  Each depth map's gradient buffer is zeroed once and then accumulated into by
-    every pair-direction that touches it (dense writes as target, atomic scatter as reference)."""
-    n_ref, n_scales = len(ref_imgs), len(tgt_depths)
+    every pair-direction that touches it (dense writes as target, scatter as reference); one call
+    into the library, pair kernels ordered on the stream, one shared scratch buffer."""
+    B, _, H, W = tgt_img.shape
+    pairs = _pair_list(tgt_img, ref_imgs, tgt_depths, ref_depths, poses, poses_inv)
+    n = len(pairs)
+    ws_bytes, scratch_bytes, _ = _sizes(lib, B, H, W)
     g_td = [torch.zeros_like(t) for t in tgt_depths]
     g_rd = [[torch.zeros_like(t) for t in r] for r in ref_depths]
-    g_poses, g_poses_inv = [], []
-    B, _, H, W = tgt_img.shape
-    scratch = pair_bwd_scratch(lib, tgt_img, B, H, W)  # shared: the calls below are ordered on one stream
-    j = 0
-    for i in range(n_ref):
-        gp_i = gpi_i = None
-        for s in range(n_scales):
-            dt, dr = tgt_depths[s], ref_depths[i][s]
-            _, _, a = pair_bwd(lib, tgt_img, ref_imgs[i], dt, dr, poses[i], K, flags, wss[j], g_photo, g_geom,
-                               g_td[s], g_rd[i][s], scratch)
-            _, _, b = pair_bwd(lib, ref_imgs[i], tgt_img, dr, dt, poses_inv[i], K, flags, wss[j + 1], g_photo, g_geom,
-                               g_rd[i][s], g_td[s], scratch)
-            gp_i = a if gp_i is None else gp_i + a
-            gpi_i = b if gpi_i is None else gpi_i + b
-            j += 2
-        g_poses.append(gp_i)
-        g_poses_inv.append(gpi_i)
+    g_pose_all = torch.empty(n, B, 6, dtype=tgt_img.dtype, device=tgt_img.device)
+    scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=tgt_img.device)
+
+    def gbuf(key):
+        return g_td[key[1]] if key[0] == "t" else g_rd[key[1]][key[2]]
+
+    descs = (PairDesc * n)()
+    wp, gp, psz = ws.data_ptr(), g_pose_all.data_ptr(), g_pose_all.element_size() * B * 6
+    for j, (ti, ri, dt, dr, po, kt, kr) in enumerate(pairs):
+        d = descs[j]
+        d.tgt_img, d.ref_img, d.tgt_depth, d.ref_depth, d.pose = ti.data_ptr(), ri.data_ptr(), dt.data_ptr(), \
+            dr.data_ptr(), po.data_ptr()
+        d.ws = wp + j * ws_bytes
+        d.g_tgt_depth, d.g_ref_depth, d.g_pose = gbuf(kt).data_ptr(), gbuf(kr).data_ptr(), gp + j * psz
+    lib.call(f"scsfm_pairs_bwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags, _p(scratch),
+             _p(g_photo), _p(g_geom), _stream(tgt_img))
+    n_scales = len(tgt_depths)
+    # pair j = 2 * (i * n_scales + s) + direction; a pose feeds every scale of its ref
+    per = g_pose_all.view(len(ref_imgs), n_scales, 2, B, 6).sum(dim=1) if n_scales > 1 else \
+        g_pose_all.view(len(ref_imgs), 2, B, 6)
+    g_poses = [per[i, 0] for i in range(len(ref_imgs))]
+    g_poses_inv = [per[i, 1] for i in range(len(ref_imgs))]
     return g_td, g_rd, g_poses, g_poses_inv
 
 
+def _ptr_array(tensors):
+    arr = (_ct.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
 def smooth_multi_fwd(lib, depths, imgs):
-    """compute_smooth_loss (loss_functions.py:154-159): sum over frames -> (loss, wss)."""
-    outs = torch.empty(len(depths), dtype=imgs[0].dtype, device=imgs[0].device)
-    wss = [smooth_fwd(lib, d, im, outs[i:i + 1])[1] for i, (d, im) in enumerate(zip(depths, imgs))]
-    return outs.sum(), wss
+    """compute_smooth_loss (loss_functions.py:154-159): sum over frames -> (loss, ws)."""
+    _chk(*depths, *imgs)
+    B, _, H, W = imgs[0].shape
+    n = len(depths)
+    for d, im in zip(depths, imgs):
+        check_sizes(d, "depth", (B, 1, H, W))
+        check_sizes(im, "img", (B, 3, H, W))
+    ws = torch.empty(n * _sizes(lib, B, H, W)[2], dtype=torch.uint8, device=imgs[0].device)
+    outs = torch.empty(n, dtype=imgs[0].dtype, device=imgs[0].device)
+    lib.call(f"scsfm_smooth_multi_fwd_{_suffix(imgs[0])}", n, _ptr_array(depths), _ptr_array(imgs), B, H, W, _p(ws),
+             _p(outs), _stream(imgs[0]))
+    return outs.sum(), ws
+
+
+def smooth_multi_bwd(lib, depths, imgs, ws, g_loss, need=None):
+    """-> list of dL/d depth (None where ``need[i]`` is False)."""
+    B, _, H, W = imgs[0].shape
+    n = len(depths)
+    grads = [torch.zeros_like(d) if (need is None or need[i]) else None for i, d in enumerate(depths)]
+    lib.call(f"scsfm_smooth_multi_bwd_{_suffix(imgs[0])}", n, _ptr_array(depths), _ptr_array(imgs), B, H, W, _p(ws),
+             _p(g_loss), _ptr_array(grads), _stream(imgs[0]))
+    return grads

@@ -65,10 +65,10 @@ class PhotoGeometryLoss(torch.autograd.Function):
         tgt_img, K = _c(tgt_img), _c(K)
         _need_cuda(tgt_img, K, *rest)
         ref_imgs, tgt_depths, ref_depths, poses, poses_inv, _ = PhotoGeometryLoss._split(rest, n_ref, n_scales)
-        photo, geom, _, wss = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
-                                                      poses_inv, group=_dist.exact_group())
+        photo, geom, _, ws = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
+                                                     poses_inv, group=_dist.exact_group())
         ctx.flags, ctx.n_ref, ctx.n_scales = flags, n_ref, n_scales
-        ctx.save_for_backward(tgt_img, K, *rest, *wss)
+        ctx.save_for_backward(tgt_img, K, *rest, ws)
         return photo, geom
 
     @staticmethod
@@ -79,9 +79,9 @@ class PhotoGeometryLoss(torch.autograd.Function):
         tgt_img, K = saved[0], saved[1]
         _no_grad_inputs(ctx, 3, ["tgt_img", "intrinsics"] + [f"ref_imgs[{i}]" for i in range(n_ref)])
         ref_imgs, tgt_depths, ref_depths, poses, poses_inv, n_in = PhotoGeometryLoss._split(saved[2:], n_ref, n_scales)
-        wss = saved[2 + n_in:]
+        ws = saved[2 + n_in]
         g_td, g_rd, g_poses, g_poses_inv = capi.photo_geometry_bwd(
-            lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, wss,
+            lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws,
             _scalar(g_photo, tgt_img), _scalar(g_geom, tgt_img))
         return (None, None, None, None, None, *([None] * n_ref), *g_td, *[g for r in g_rd for g in r], *g_poses,
                 *g_poses_inv)
@@ -125,9 +125,9 @@ class SmoothLoss(torch.autograd.Function):
         rest = [_c(t) for t in rest]
         _need_cuda(*rest)
         depths, imgs = rest[:n], rest[n:]
-        loss, wss = capi.smooth_multi_fwd(lib, depths, imgs)
+        loss, ws = capi.smooth_multi_fwd(lib, depths, imgs)
         ctx.n = n
-        ctx.save_for_backward(*rest, *wss)
+        ctx.save_for_backward(*rest, ws)
         return loss
 
     @staticmethod
@@ -135,12 +135,10 @@ class SmoothLoss(torch.autograd.Function):
         lib = _lib.get()
         n = ctx.n
         saved = ctx.saved_tensors
-        depths, imgs, wss = saved[:n], saved[n:2 * n], saved[2 * n:]
+        depths, imgs, ws = saved[:n], saved[n:2 * n], saved[2 * n]
         if any(ctx.needs_input_grad[1 + n:]):
             raise NotImplementedError("scsfm_hip: no gradient for images")
-        gl = _scalar(g, imgs[0])
-        grads = [capi.smooth_bwd(lib, d, im, ws, gl) if ctx.needs_input_grad[1 + i] else None
-                 for i, (d, im, ws) in enumerate(zip(depths, imgs, wss))]
+        grads = capi.smooth_multi_bwd(lib, depths, imgs, ws, _scalar(g, imgs[0]), ctx.needs_input_grad[1:1 + n])
         return (None, *grads, *([None] * n))
 
 

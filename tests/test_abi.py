@@ -12,6 +12,9 @@ EXPECTED = {
     "scsfm_abi_version",
     "scsfm_pair_ws_bytes", "scsfm_pair_bwd_scratch_bytes", "scsfm_pair_fwd_f32", "scsfm_pair_bwd_f32", "scsfm_pair_refinalize_f32",
     "scsfm_pair_fwd_f64", "scsfm_pair_bwd_f64", "scsfm_pair_refinalize_f64",
+    "scsfm_pairs_fwd_f32", "scsfm_pairs_bwd_f32", "scsfm_pairs_fwd_f64", "scsfm_pairs_bwd_f64",
+    "scsfm_smooth_multi_fwd_f32", "scsfm_smooth_multi_bwd_f32", "scsfm_smooth_multi_fwd_f64",
+    "scsfm_smooth_multi_bwd_f64",
     "scsfm_warp_ws_bytes", "scsfm_warp_fwd_f32", "scsfm_warp_bwd_f32", "scsfm_warp_fwd_f64", "scsfm_warp_bwd_f64",
     "scsfm_pose_vec2mat_fwd_f32", "scsfm_pose_vec2mat_bwd_f32", "scsfm_pose_vec2mat_fwd_f64",
     "scsfm_pose_vec2mat_bwd_f64",
@@ -29,6 +32,7 @@ def test_header_declares_the_expected_entry_points():
     # raw pointers and sizes only: the parser maps every argument to int / unsigned / size_t / void*
     restype, argtypes = decls["scsfm_pair_fwd_f32"]
     assert len(argtypes) == 13
+    assert len(decls["scsfm_pair_bwd_f32"][1]) == 18
 
 
 def test_hostsim_build_exports_every_symbol():

@@ -181,8 +181,8 @@ def test_total_loss_fp32_matches_reference_goldens(lib, name):
                 for i in range(2):
                     rd_full[i][s].backward(g_rd[i][s]) if s > 0 else None
             frames = [td[0]] + [r[0] for r in rd]
-            g_sm = [capi.smooth_bwd(lib, f.detach(), im, w, torch.tensor([0.1]))
-                    for f, im, w in zip(frames, [d["tgt_img"]] + d["ref_imgs"], sws)]
+            g_sm = capi.smooth_multi_bwd(lib, [f.detach() for f in frames], [d["tgt_img"]] + d["ref_imgs"], sws,
+                                         torch.tensor([0.1]))
             tot_t0 = g_td[0] + g_sm[0]
             ref = gold[f"{key}/g_tgt_depth_s0"]
             assert_close_frac(tot_t0.numpy(), ref, atol=2e-3 * np.abs(ref).max(), rtol=1e-3, max_bad_frac=2e-3,
@@ -217,7 +217,8 @@ def test_smooth_matches_oracle_and_golden(lib):
     imgs = [d["tgt_img"]] + d["ref_imgs"]
     loss, wss = capi.smooth_multi_fwd(lib, frames, imgs)
     assert abs(float(loss) - float(gold["smooth_only/loss"])) <= 1e-5
-    g0 = capi.smooth_bwd(lib, frames[0], imgs[0], wss[0], torch.ones(1))
+    g0, g1, g2 = capi.smooth_multi_bwd(lib, frames, imgs, wss, torch.ones(1), need=[True, False, True])
+    assert g1 is None and g2 is not None
     assert_close_frac(g0.numpy(), gold["smooth_only/g_tgt_depth"], atol=1e-5 * np.abs(gold["smooth_only/g_tgt_depth"]).max(),
                       rtol=1e-4)
 
