@@ -107,14 +107,9 @@ def time_kernels(x, flags, iters):
         "pair_bwd": lambda: capi.pair_bwd(lib, *a, fl, ws, one, one, g_t, g_r, scratch),
         "pair_bwd_photo_only": lambda: capi.pair_bwd(lib, *a, fl | SKIP_GEOM, ws, one, one, g_t, g_r, scratch),
         "pair_bwd_geom_only": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO, ws, one, one, g_t, g_r, scratch),
-        "fwd_nossim": lambda: capi.pair_fwd_into(lib, *a, fl | 1024, out),
-        "fwd_noring": lambda: capi.pair_fwd_into(lib, *a, fl | 2048, out),
-        "fwd_nocolour": lambda: capi.pair_fwd_into(lib, *a, fl | 8192, out),
-        "fwd_none": lambda: capi.pair_fwd_into(lib, *a, fl | 1024 | 2048 | 8192, out),
-        "photo_nossim": lambda: capi.pair_bwd(lib, *a, fl | SKIP_GEOM | 1024, ws, one, one, g_t, g_r, scratch),
-        "photo_noring": lambda: capi.pair_bwd(lib, *a, fl | SKIP_GEOM | 2048, ws, one, one, g_t, g_r, scratch),
-        "photo_nocolour": lambda: capi.pair_bwd(lib, *a, fl | SKIP_GEOM | 8192, ws, one, one, g_t, g_r, scratch),
-        "photo_none": lambda: capi.pair_bwd(lib, *a, fl | SKIP_GEOM | 1024 | 2048 | 8192, ws, one, one, g_t, g_r, scratch),
+        "pair_fwd_spec": lambda: lib.call("scsfm_pair_fwd_spec_f32", B, H, W, *[t.data_ptr() for t in a], fl,
+                                          ws.data_ptr(), scratch.data_ptr(), 1.0, 0.5, out.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream),
         "geom_noscatter": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | 1024, ws, one, one, g_t, g_r, scratch),
         "geom_nodense": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | 2048, ws, one, one, g_t, g_r, scratch),
         "geom_noreduce": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | 4096, ws, one, one, g_t, g_r, scratch),

@@ -79,6 +79,21 @@ int scsfm_abi_version(void);
 size_t scsfm_pair_ws_bytes(int B, int H, int W);
 size_t scsfm_pair_bwd_scratch_bytes(int B, int H, int W);
 
+/* Speculative forward: same results in `out` / `ws` as scsfm_pair_fwd, but computed by the backward's
+ * tiled pass, which also leaves dL/d(warped colours) and dL/d(diff_depth) in `gbuf` up to the factor
+ * g_photo / (3 S_mask) -- valid if the upstream gradients of (photo, geom) later stand in the ratio
+ * w_photo : w_geom (the loss weights, train.py:268; w_photo != 0).  scsfm_pair_bwd must then be
+ * given the same `gbuf` as its `scratch`; it verifies the ratio on the device and silently falls
+ * back to recomputing the pass when it does not hold.  One warp + SSIM evaluation less per pair. */
+int scsfm_pair_fwd_spec_f32(int B, int H, int W, const float* tgt_img, const float* ref_img,
+                            const float* tgt_depth, const float* ref_depth, const float* pose,
+                            const float* intrinsics, unsigned flags, void* ws, void* gbuf, double w_photo,
+                            double w_geom, float* out, void* stream);
+int scsfm_pair_fwd_spec_f64(int B, int H, int W, const double* tgt_img, const double* ref_img,
+                            const double* tgt_depth, const double* ref_depth, const double* pose,
+                            const double* intrinsics, unsigned flags, void* ws, void* gbuf, double w_photo,
+                            double w_geom, double* out, void* stream);
+
 int scsfm_pair_fwd_f32(int B, int H, int W, const float* tgt_img, const float* ref_img,
                        const float* tgt_depth, const float* ref_depth, const float* pose,
                        const float* intrinsics, unsigned flags, void* ws, float* out, void* stream);
@@ -117,15 +132,17 @@ typedef struct scsfm_pair_desc {
   void* g_tgt_depth;
   void* g_ref_depth;
   void* g_pose;
+  void* gbuf; /* NULL, or scsfm_pair_bwd_scratch_bytes(B,H,W) bytes private to this pair, alive from the
+                 forward to the backward: enables the speculative forward (see scsfm_pair_fwd_spec) */
 } scsfm_pair_desc;
 
 int scsfm_pairs_fwd_f32(int n, const scsfm_pair_desc* d, int B, int H, int W, const float* intrinsics,
-                        unsigned flags, void* stream);
+                        unsigned flags, double w_photo, double w_geom, void* stream);
 int scsfm_pairs_bwd_f32(int n, const scsfm_pair_desc* d, int B, int H, int W, const float* intrinsics,
                         unsigned flags, void* scratch, const float* g_photo, const float* g_geom,
                         void* stream);
 int scsfm_pairs_fwd_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, const double* intrinsics,
-                        unsigned flags, void* stream);
+                        unsigned flags, double w_photo, double w_geom, void* stream);
 int scsfm_pairs_bwd_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, const double* intrinsics,
                         unsigned flags, void* scratch, const double* g_photo, const double* g_geom,
                         void* stream);

@@ -40,7 +40,9 @@ struct BatchConsts {
 
 // Workspace layout of one pair-direction call (scsfm_pair_ws_bytes).
 //   [0]                consts   : B x BatchConsts<double>-sized slots (T = float uses the front)
-//   [off_sums]         sums     : double[8] = {S_photo, S_geom, S_m, photo, geom, a, b, -}
+//   [off_sums]         sums     : double[16] = {S_photo, S_geom, S_m, photo, geom, a, b, -, spec, w_photo, w_geom, ...}
+//                                 a = d photo / d sum, b = d geom / d sum (0 when gated off); spec = 1 if the
+//                                 forward was speculative for upstream weights (w_photo, w_geom)
 //   [off_gP]           gPp      : double[B][geom blocks per image][12]  (per-block partial gradients of A|c;
 //                                 reduced by pose_reduce_bwd_kernel -- same-address atomics from ~200 blocks per
 //                                 image cost 60 us per launch, partials cost nothing)
@@ -63,9 +65,10 @@ inline PairWs pair_ws_layout(int B, int H, int W) {
   l.nbx = ceil_div(W, kTileW);
   l.nby = ceil_div(H, kTileH);
   size_t off = (size_t)B * sizeof(BatchConsts<double>);
-  l.off_sums = off; off += 8 * sizeof(double);
+  l.off_sums = off; off += 16 * sizeof(double);
   l.off_gP = off; off += (size_t)B * ceil_div(W, kWave) * ceil_div(H, 16) * 12 * sizeof(double);
-  l.off_partials = off; off += (size_t)l.nbx * l.nby * B * 3 * sizeof(double);
+  // partials: sized for the finest tiling that writes them (62 x 6 outputs per block: the fp64 speculative forward)
+  l.off_partials = off; off += (size_t)ceil_div(W, kTileW - 2) * ceil_div(H, 6) * B * 3 * sizeof(double);
   l.total = (off + 255) & ~(size_t)255;
   return l;
 }

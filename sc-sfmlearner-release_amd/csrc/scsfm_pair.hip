@@ -31,7 +31,6 @@ __device__ __forceinline__ Sample<T> warp_colours(const BatchConsts<T>& bc, int 
   T t[4];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    if (flags & SCSFM_DEBUG_X4) { xy[c] = make2(tgt_img[c * plane + p], T(0)); continue; }  // profiling only
     load_taps(ref_img + c * plane, s, t);
     xy[c] = make2(tgt_img[c * plane + p], bilerp(t, s));
   }
@@ -101,7 +100,7 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(
   }
   // ---- phase 1b: the 1-pixel ring (SSIM windows of the tile's border pixels) ------------------
   if (kSsim) {
-    if (threadIdx.x < 2 * kHaloW + 2 * TH && !(flags & SCSFM_DEBUG_X2)) {
+    if (threadIdx.x < 2 * kHaloW + 2 * TH) {
       int hy, hx;
       ring_pos<TH>(threadIdx.x, hy, hx);
       const int u = reflect_index(tx0 + hx - 1, W), v = reflect_index(ty0 + hy - 1, H);
@@ -117,15 +116,13 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(
 #pragma unroll
   for (int k = 0; k < STRIP; ++k) photo[k] = kSsim ? T(0.15) * l1sum[k] : l1sum[k];  // loss_functions.py:109
   if constexpr (kSsim) {
-    if (!(flags & SCSFM_DEBUG_X1)) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        WinSums<T> ws[STRIP];
-        V2 centre[STRIP];
-        strip_window_sums<T, STRIP>(sXY[c], strip * STRIP, col, ws, centre);
+    for (int c = 0; c < 3; ++c) {
+      WinSums<T> ws[STRIP];
+      V2 centre[STRIP];
+      strip_window_sums<T, STRIP>(sXY[c], strip * STRIP, col, ws, centre);
 #pragma unroll
-        for (int k = 0; k < STRIP; ++k) photo[k] += T(0.85) * clamp01(ssim_stats(ws[k]).raw);
-      }
+      for (int k = 0; k < STRIP; ++k) photo[k] += T(0.85) * clamp01(ssim_stats(ws[k]).raw);
     }
   }
   T acc_p = T(0), acc_g = T(0), acc_m = T(0);
@@ -165,14 +162,18 @@ __device__ __forceinline__ void publish_losses(double Sp, double Sg, double Sm, 
 // the coefficients the backward multiplies the upstream gradients with.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(int nblocks, const double* __restrict__ partials,
-                                                                 double* __restrict__ sums, T* __restrict__ out) {
+                                                                 double* __restrict__ sums, T* __restrict__ out,
+                                                                 double spec, double w_photo, double w_geom) {
   __shared__ double red[3 * (kThreads / kWave)];
   double v[3] = {0, 0, 0};
   for (int i = threadIdx.x; i < nblocks; i += kThreads) {
     v[0] += partials[3 * i]; v[1] += partials[3 * i + 1]; v[2] += partials[3 * i + 2];
   }
   block_sum<3>(v, red);
-  if (threadIdx.x == 0) publish_losses(v[0], v[1], v[2], sums, out);
+  if (threadIdx.x == 0) {
+    publish_losses(v[0], v[1], v[2], sums, out);
+    sums[8] = spec; sums[9] = w_photo; sums[10] = w_geom;
+  }
 }
 
 // Data-parallel "exact" mode: the caller all-reduces out[2..4] (the three raw sums)
@@ -193,21 +194,43 @@ __global__ void pair_refinalize_kernel(double* __restrict__ sums, T* __restrict_
 // Splitting here keeps both halves at a register budget that sustains >= 4 waves per SIMD; fused,
 // the kernel needed 256 VGPRs (1 wave per SIMD) and could not hide its gather latency.
 // ==========================================================================================
-template <typename T, bool kSsim>
+//
+// kSpec = true is the SPECULATIVE FORWARD: the same kernel run as the forward pass, with unit photo
+// coefficient and the geometry / photo coefficient ratio r = 3 w_geom / w_photo the caller expects the
+// upstream gradients to have (the loss weights are constants of a training run, train.py:268).  It
+// produces the three sums of the forward AND the four gradient planes up to the common factor
+// a = g_photo / (3 S_m), which is only known after the reduction; the backward then starts directly at
+// pass B with that factor.  If the upstream gradients turn out different (spec_valid), pass A is
+// re-run normally.  This removes one full warp + SSIM recomputation per pair-direction.
+template <typename T>
+__device__ __forceinline__ bool spec_valid(const double* __restrict__ sums, const T* __restrict__ g_photo,
+                                           const T* __restrict__ g_geom) {
+  if (sums[8] == 0.0) return false;          // the forward was not speculative
+  if (sums[5] == 0.0) return true;           // photo gate closed: every gradient is zero
+  const double gate_g = sums[6] != 0.0 ? 1.0 : 0.0;
+  return double(g_geom[0]) * gate_g * sums[9] == double(g_photo[0]) * sums[10];  // products of floats: exact
+}
+
+template <typename T, bool kSsim, bool kSpec>
 __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
     int H, int W, unsigned flags, const T* __restrict__ tgt_img, const T* __restrict__ ref_img,
     const T* __restrict__ tgt_depth, const T* __restrict__ ref_depth, const BatchConsts<T>* __restrict__ consts,
     const double* __restrict__ sums, const T* __restrict__ g_photo, const T* __restrict__ g_geom,
-    T* __restrict__ gbuf) {
+    T* __restrict__ gbuf, T r_hint, double* __restrict__ partials) {
   typedef typename Vec2<T>::type V2;
   constexpr int TH = Tile<T>::kH, STRIP = TH / (kThreads / kWave);
   __shared__ V2 sXY[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];
   __shared__ T sG[kSsim ? 3 : 1][kSsim ? TH : 1][kSsim ? kTileW : 1];  // 1/9 (g_mu_y, g_E[y^2], g_E[xy]), one colour
+  __shared__ double red[kSpec ? 3 * (kThreads / kWave) : 1];
 
   // upstream gradient x d(masked mean)/d(sum): zero when the 10000-pixel gate was closed
-  const T a = T(sums[5]) * g_photo[0];
-  const T bg = T(sums[6]) * g_geom[0];
-  if (a == T(0) && bg == T(0)) return;  // workgroup-uniform: pass B skips as well
+  T a = T(1), bg = r_hint;
+  if constexpr (!kSpec) {
+    a = T(sums[5]) * g_photo[0];
+    bg = T(sums[6]) * g_geom[0];
+    if (a == T(0) && bg == T(0)) return;        // workgroup-uniform: pass B skips as well
+    if (spec_valid(sums, g_photo, g_geom)) return;  // the forward already left the planes in gbuf
+  }
 
   const int b = blockIdx.z, col = threadIdx.x & (kWave - 1), strip = threadIdx.x / kWave;
   // the 64 x TH compute domain starts one pixel before the 62 x (TH-2) block of outputs
@@ -227,6 +250,7 @@ __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
   T coef[STRIP];  // a * m * (1 - dd): weight of blend_c(q) in the loss
   T mq[STRIP];    // mask of the owned pixel
   T bsum[STRIP];  // sum_c blend_c of the owned pixel
+  T ddq[kSpec ? STRIP : 1];  // diff_depth of the owned pixel (forward sums)
   V2 cen[kSsim ? 1 : STRIP][kSsim ? 1 : 3];
   // ---- phase 1a ------------------------------------------------------------------------------
 #pragma unroll
@@ -247,10 +271,11 @@ __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
     mq[k] = inimg ? pixel_mask(s, with_auto, xy, ref_img, plane, unsigned(v) * unsigned(W) + unsigned(u)) : T(0);
     coef[k] = a * mq[k] * (with_mask ? (T(1) - ddk) : T(1));
     bsum[k] = T(0);
+    if constexpr (kSpec) ddq[k] = ddk;
   }
   // ---- phase 1b: ring ------------------------------------------------------------------------
   if constexpr (kSsim) {
-    if (threadIdx.x < 2 * kHaloW + 2 * TH && !(flags & SCSFM_DEBUG_X2)) {
+    if (threadIdx.x < 2 * kHaloW + 2 * TH) {
       int hy, hx;
       ring_pos<TH>(threadIdx.x, hy, hx);
       const int u = reflect_index(ox + hx - 1, W), v = reflect_index(oy + hy - 1, H);
@@ -265,10 +290,7 @@ __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     T gI[STRIP];
-    if (flags & SCSFM_DEBUG_X1) {  // profiling only
-#pragma unroll
-      for (int k = 0; k < STRIP; ++k) gI[k] = coef[k];
-    } else if constexpr (kSsim) {
+    if constexpr (kSsim) {
       // phase 2: forward statistics at every owned pixel q; publish 1/9 (g_mu_y, g_E[y^2], g_E[xy])(q)
       WinSums<T> ws[STRIP];
       V2 centre[STRIP];
@@ -320,6 +342,23 @@ __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
       gbuf[3 * gplane + unsigned(py) * unsigned(W) + unsigned(px)] =
           bg * mq[k] - (with_mask ? a * mq[k] * bsum[k] : T(0));
   }
+  if constexpr (kSpec) {  // the forward's three sums over the pixels this block owns
+    T v[3] = {T(0), T(0), T(0)};
+#pragma unroll
+    for (int k = 0; k < STRIP; ++k) {
+      const int ly = strip * STRIP + k, py = py0 + k;
+      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) {
+        v[0] += bsum[k] * (with_mask ? (T(1) - ddq[k]) : T(1)) * mq[k];
+        v[1] += ddq[k] * mq[k];
+        v[2] += mq[k];
+      }
+    }
+    block_sum<3>(v, red);
+    if (threadIdx.x == 0) {
+      double* o = partials + 3 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+      o[0] = double(v[0]); o[1] = double(v[1]); o[2] = double(v[2]);
+    }
+  }
 }
 
 // ==========================================================================================
@@ -339,6 +378,8 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
   __shared__ T win[kWinH][kWinW];  // staging window of the scatter into dL/d ref_depth
   __shared__ int win_org[2];
   if (T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0)) return;  // as in pass A
+  // planes left by a speculative forward lack the common factor a = g_photo / (3 S_m)
+  const T gscale = spec_valid(sums, g_photo, g_geom) ? T(sums[5]) * g_photo[0] : T(1);
   const int b = blockIdx.z;
   const int px = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
   const int py0 = (blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave) * ROWS;
@@ -370,7 +411,8 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
     if (px >= W || py >= H) continue;
     const unsigned p = unsigned(py) * unsigned(W) + unsigned(px);
     const T d = tgt_depth[p];
-    const T gI0 = gbuf[p], gI1 = gbuf[gplane + p], gI2 = gbuf[2 * gplane + p], g_dd = gbuf[3 * gplane + p];
+    const T gI0 = gscale * gbuf[p], gI1 = gscale * gbuf[gplane + p], gI2 = gscale * gbuf[2 * gplane + p],
+            g_dd = gscale * gbuf[3 * gplane + p];
     const Sample<T> s = project_pixel(bc, px, py, d, H, W, flags);
     const SampleGrad<T> sg = sample_grad(s);
     T t[4];
@@ -439,7 +481,38 @@ static int pair_fwd(int B, int H, int W, const T* tgt_img, const T* ref_img, con
     hipLaunchKernelGGL((pair_fwd_kernel<T, false>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img, ref_img,
                        tgt_depth, ref_depth, (const BatchConsts<T>*)consts, partials);
   hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(1), dim3(kThreads), 0, stream, (int)(grid.x * grid.y * grid.z),
-                     (const double*)partials, sums, out);
+                     (const double*)partials, sums, out, 0.0, 0.0, 0.0);
+  return launch_status();
+}
+
+// Forward that also leaves the backward's pass-A planes in `gbuf` (see pair_bwd_photo_kernel, kSpec).
+template <typename T>
+static int pair_fwd_spec(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth,
+                         const T* ref_depth, const T* pose, const T* K, unsigned flags, void* ws, void* gbuf,
+                         double w_photo, double w_geom, T* out, void* stream_) {
+  clear_status();
+  if (B <= 0 || H < 2 || W < 2 || !tgt_img || !ref_img || !tgt_depth || !ref_depth || !pose || !K || !ws || !out ||
+      !gbuf || w_photo == 0.0)
+    return SCSFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const PairWs l = pair_ws_layout(B, H, W);
+  char* base = reinterpret_cast<char*>(ws);
+  auto* consts = reinterpret_cast<BatchConsts<T>*>(base);
+  double* sums = reinterpret_cast<double*>(base + l.off_sums);
+  double* partials = reinterpret_cast<double*>(base + l.off_partials);
+  hipLaunchKernelGGL((prep_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, consts);
+  dim3 grid(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), B);
+  const T r_hint = T(3.0 * w_geom / w_photo);
+  if (flags & SCSFM_WITH_SSIM)
+    hipLaunchKernelGGL((pair_bwd_photo_kernel<T, true, true>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img,
+                       ref_img, tgt_depth, ref_depth, (const BatchConsts<T>*)consts, (const double*)sums,
+                       (const T*)nullptr, (const T*)nullptr, reinterpret_cast<T*>(gbuf), r_hint, partials);
+  else
+    hipLaunchKernelGGL((pair_bwd_photo_kernel<T, false, true>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img,
+                       ref_img, tgt_depth, ref_depth, (const BatchConsts<T>*)consts, (const double*)sums,
+                       (const T*)nullptr, (const T*)nullptr, reinterpret_cast<T*>(gbuf), r_hint, partials);
+  hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(1), dim3(kThreads), 0, stream, (int)(grid.x * grid.y * grid.z),
+                     (const double*)partials, sums, out, 1.0, w_photo, w_geom);
   return launch_status();
 }
 
@@ -461,11 +534,11 @@ static int pair_bwd(int B, int H, int W, const T* tgt_img, const T* ref_img, con
   dim3 grid(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), B);
   if (flags & SCSFM_DEBUG_SKIP_PHOTO) {
   } else if (flags & SCSFM_WITH_SSIM)
-    hipLaunchKernelGGL((pair_bwd_photo_kernel<T, true>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img,
-                       ref_img, tgt_depth, ref_depth, consts, sums, g_photo, g_geom, gbuf);
+    hipLaunchKernelGGL((pair_bwd_photo_kernel<T, true, false>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img,
+                       ref_img, tgt_depth, ref_depth, consts, sums, g_photo, g_geom, gbuf, T(0), (double*)nullptr);
   else
-    hipLaunchKernelGGL((pair_bwd_photo_kernel<T, false>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img,
-                       ref_img, tgt_depth, ref_depth, consts, sums, g_photo, g_geom, gbuf);
+    hipLaunchKernelGGL((pair_bwd_photo_kernel<T, false, false>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img,
+                       ref_img, tgt_depth, ref_depth, consts, sums, g_photo, g_geom, gbuf, T(0), (double*)nullptr);
   dim3 grid_b(ceil_div(W, kWave), ceil_div(H, 4 * (kThreads / kWave)), B);
   if (!(flags & SCSFM_DEBUG_SKIP_GEOM))
     hipLaunchKernelGGL((pair_bwd_geom_kernel<T>), grid_b, dim3(kThreads), 0, stream, H, W, flags, ref_img, tgt_depth,
@@ -496,22 +569,23 @@ size_t scsfm_pair_bwd_scratch_bytes(int B, int H, int W) {
 
 size_t scsfm_pair_ws_bytes(int B, int H, int W) {
   if (B <= 0 || H < 2 || W < 2) return 0;
-  // sized for the smaller (fp64) tile so that one workspace serves both precisions
-  scsfm::PairWs l = scsfm::pair_ws_layout(B, H, W);
-  size_t nb = (size_t)scsfm::ceil_div(W, scsfm::kTileW) * scsfm::ceil_div(H, scsfm::Tile<double>::kH) * B;
-  return (l.off_partials + nb * 3 * sizeof(double) + 255) & ~(size_t)255;
+  return scsfm::pair_ws_layout(B, H, W).total;  // sized for both precisions and both forward kernels
 }
 
 // Several pair-directions per call: one trip through the binding layer per step instead of one per
 // pair (the per-call host cost of a ctypes round trip, ~25 us, is comparable to a kernel here).
 #define SCSFM_PAIRS_API(SUF, T)                                                                                       \
   int scsfm_pairs_fwd_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,          \
-                            void* stream) {                                                                           \
+                            double w_photo, double w_geom, void* stream) {                                            \
     if (n < 0 || (n > 0 && !d)) return SCSFM_ERR_ARG;                                                                 \
     for (int i = 0; i < n; ++i) {                                                                                     \
-      int rc = scsfm::pair_fwd<T>(B, H, W, (const T*)d[i].tgt_img, (const T*)d[i].ref_img, (const T*)d[i].tgt_depth,  \
-                                  (const T*)d[i].ref_depth, (const T*)d[i].pose, K, flags, d[i].ws, (T*)d[i].out,     \
-                                  stream);                                                                            \
+      int rc = (d[i].gbuf && w_photo != 0.0)                                                                          \
+                   ? scsfm::pair_fwd_spec<T>(B, H, W, (const T*)d[i].tgt_img, (const T*)d[i].ref_img,                 \
+                                             (const T*)d[i].tgt_depth, (const T*)d[i].ref_depth, (const T*)d[i].pose, \
+                                             K, flags, d[i].ws, d[i].gbuf, w_photo, w_geom, (T*)d[i].out, stream)     \
+                   : scsfm::pair_fwd<T>(B, H, W, (const T*)d[i].tgt_img, (const T*)d[i].ref_img,                      \
+                                        (const T*)d[i].tgt_depth, (const T*)d[i].ref_depth, (const T*)d[i].pose, K,   \
+                                        flags, d[i].ws, (T*)d[i].out, stream);                                        \
       if (rc) return rc;                                                                                              \
     }                                                                                                                 \
     return SCSFM_OK;                                                                                                  \
@@ -521,8 +595,9 @@ size_t scsfm_pair_ws_bytes(int B, int H, int W) {
     if (n < 0 || (n > 0 && !d)) return SCSFM_ERR_ARG;                                                                 \
     for (int i = 0; i < n; ++i) {                                                                                     \
       int rc = scsfm::pair_bwd<T>(B, H, W, (const T*)d[i].tgt_img, (const T*)d[i].ref_img, (const T*)d[i].tgt_depth,  \
-                                  (const T*)d[i].ref_depth, (const T*)d[i].pose, K, flags, d[i].ws, scratch, g_photo, \
-                                  g_geom, (T*)d[i].g_tgt_depth, (T*)d[i].g_ref_depth, (T*)d[i].g_pose, stream);       \
+                                  (const T*)d[i].ref_depth, (const T*)d[i].pose, K, flags, d[i].ws,                   \
+                                  d[i].gbuf ? d[i].gbuf : scratch, g_photo, g_geom, (T*)d[i].g_tgt_depth,             \
+                                  (T*)d[i].g_ref_depth, (T*)d[i].g_pose, stream);                                     \
       if (rc) return rc;                                                                                              \
     }                                                                                                                 \
     return SCSFM_OK;                                                                                                  \
@@ -532,6 +607,12 @@ SCSFM_PAIRS_API(f32, float)
 SCSFM_PAIRS_API(f64, double)
 
 #define SCSFM_PAIR_API(SUF, T)                                                                                        \
+  int scsfm_pair_fwd_spec_##SUF(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth,          \
+                                const T* ref_depth, const T* pose, const T* K, unsigned flags, void* ws, void* gbuf,  \
+                                double w_photo, double w_geom, T* out, void* stream) {                                \
+    return scsfm::pair_fwd_spec<T>(B, H, W, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, ws, gbuf,         \
+                                   w_photo, w_geom, out, stream);                                                     \
+  }                                                                                                                   \
   int scsfm_pair_fwd_##SUF(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth,               \
                            const T* ref_depth, const T* pose, const T* K, unsigned flags, void* ws, T* out,           \
                            void* stream) {                                                                            \

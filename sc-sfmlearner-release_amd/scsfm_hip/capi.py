@@ -229,7 +229,7 @@ import functools as _ft
 class PairDesc(_ct.Structure):
     """scsfm_pair_desc of include/scsfm_hip.h."""
     _fields_ = [(n, _ct.c_void_p) for n in ("tgt_img", "ref_img", "tgt_depth", "ref_depth", "pose", "ws", "out",
-                                            "g_tgt_depth", "g_ref_depth", "g_pose")]
+                                            "g_tgt_depth", "g_ref_depth", "g_pose", "gbuf")]
 
 
 @_ft.lru_cache(maxsize=64)
@@ -250,10 +250,15 @@ def _pair_list(tgt_img, ref_imgs, tgt_depths, ref_depths, poses, poses_inv):
     return pairs
 
 
-def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, group=None):
+def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, group=None,
+                       hint=None):
     """All pair-directions of loss_functions.py:56-90 in ONE call into the library.  ``tgt_depths[s]``
     and ``ref_depths[i][s]`` are full-resolution maps.  Returns (photo, geom, outs [n_pairs, 8], ws)
     where ``ws`` (one tensor, n_pairs slices) must reach photo_geometry_bwd untouched.
+
+    ``hint`` = (w_photo, w_geom): run the speculative forward (scsfm_pair_fwd_spec) -- the backward's
+    tiled pass doubles as the forward and leaves its output planes in ``ws``'s tail for the backward,
+    valid if the upstream gradients later stand in that ratio (checked on the device).
 
     ``group``: a torch.distributed process group -> exact data-parallel mode: the three raw sums of
     every pair are all-reduced (one [n_pairs, 3] collective) and the masked means are re-evaluated on
@@ -271,8 +276,10 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         check_sizes(d, "depth", (B, 1, H, W))
     for p in list(poses) + list(poses_inv):
         check_sizes(p, "pose", (B, 6))
-    ws_bytes = _sizes(lib, B, H, W)[0]
-    ws = torch.empty(n * ws_bytes, dtype=torch.uint8, device=tgt_img.device)
+    ws_bytes, scratch_bytes, _ = _sizes(lib, B, H, W)
+    spec = hint is not None and float(hint[0]) != 0.0
+    stride = ws_bytes + (scratch_bytes if spec else 0)  # per pair: workspace, then (speculative) the gbuf planes
+    ws = torch.empty(n * stride, dtype=torch.uint8, device=tgt_img.device)
     outs = torch.empty(n, 8, dtype=tgt_img.dtype, device=tgt_img.device)
     descs = (PairDesc * n)()
     wp, op, esz = ws.data_ptr(), outs.data_ptr(), outs.element_size() * 8
@@ -280,15 +287,17 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         d = descs[j]
         d.tgt_img, d.ref_img, d.tgt_depth, d.ref_depth, d.pose = ti.data_ptr(), ri.data_ptr(), dt.data_ptr(), \
             dr.data_ptr(), po.data_ptr()
-        d.ws, d.out = wp + j * ws_bytes, op + j * esz
-    lib.call(f"scsfm_pairs_fwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags, _stream(tgt_img))
+        d.ws, d.out = wp + j * stride, op + j * esz
+        d.gbuf = wp + j * stride + ws_bytes if spec else None
+    lib.call(f"scsfm_pairs_fwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags,
+             float(hint[0]) if spec else 0.0, float(hint[1]) if spec else 0.0, _stream(tgt_img))
     if group is not None:
         import torch.distributed as dist
         sums = outs[:, 2:5].contiguous()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
         outs[:, 2:5] = sums
         for j in range(n):
-            pair_refinalize(lib, (B, H, W), ws[j * ws_bytes:(j + 1) * ws_bytes], outs[j])
+            pair_refinalize(lib, (B, H, W), ws[j * stride:j * stride + ws_bytes], outs[j])
     tot = outs[:, :2].sum(dim=0)  # plain sums over refs, scales and directions (loss_functions.py:89-90)
     return tot[0], tot[1], outs, ws
 
@@ -303,6 +312,8 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
     pairs = _pair_list(tgt_img, ref_imgs, tgt_depths, ref_depths, poses, poses_inv)
     n = len(pairs)
     ws_bytes, scratch_bytes, _ = _sizes(lib, B, H, W)
+    spec = ws.numel() == n * (ws_bytes + scratch_bytes)  # the forward was speculative: gbuf follows each workspace
+    stride = ws_bytes + (scratch_bytes if spec else 0)
     g_td = [torch.zeros_like(t) for t in tgt_depths]
     g_rd = [[torch.zeros_like(t) for t in r] for r in ref_depths]
     g_pose_all = torch.empty(n, B, 6, dtype=tgt_img.dtype, device=tgt_img.device)
@@ -317,7 +328,8 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         d = descs[j]
         d.tgt_img, d.ref_img, d.tgt_depth, d.ref_depth, d.pose = ti.data_ptr(), ri.data_ptr(), dt.data_ptr(), \
             dr.data_ptr(), po.data_ptr()
-        d.ws = wp + j * ws_bytes
+        d.ws = wp + j * stride
+        d.gbuf = wp + j * stride + ws_bytes if spec else None
         d.g_tgt_depth, d.g_ref_depth, d.g_pose = gbuf(kt).data_ptr(), gbuf(kr).data_ptr(), gp + j * psz
     lib.call(f"scsfm_pairs_bwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags, _p(scratch),
              _p(g_photo), _p(g_geom), _stream(tgt_img))

@@ -1,0 +1,19 @@
+"""Run-time knobs of the HIP loss path."""
+from __future__ import annotations
+
+# (w_photo, w_geom): the weights the training loop multiplies photo_loss and geometry_loss with
+# (train.py:268, defaults -p 1 -c 0.5 of scripts/train_resnet18_depth_256.sh).  With a hint the
+# forward of compute_photo_and_geometry_loss already runs the backward's tiled pass (speculative
+# forward, see include/scsfm_hip.h: scsfm_pair_fwd_spec).  A wrong hint costs time, never
+# correctness: the backward checks the actual upstream gradients on the device and recomputes.
+_hint = (1.0, 0.5)
+
+
+def set_weight_hint(w_photo, w_geom):
+    """Tell the loss which upstream-gradient ratio to speculate on; ``None, None`` disables it."""
+    global _hint
+    _hint = None if w_photo is None else (float(w_photo), float(w_geom))
+
+
+def weight_hint():
+    return _hint

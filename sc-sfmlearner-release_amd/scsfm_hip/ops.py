@@ -59,14 +59,16 @@ class PhotoGeometryLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, flags, n_ref, n_scales, tgt_img, K, *rest):
-        from . import dist as _dist
+        from . import config as _config, dist as _dist
         lib = _lib.get()
         rest = [_c(t) for t in rest]
         tgt_img, K = _c(tgt_img), _c(K)
         _need_cuda(tgt_img, K, *rest)
         ref_imgs, tgt_depths, ref_depths, poses, poses_inv, _ = PhotoGeometryLoss._split(rest, n_ref, n_scales)
+        # speculate only when a backward can follow (some depth / pose requires grad)
+        hint = _config.weight_hint() if any(ctx.needs_input_grad) else None
         photo, geom, _, ws = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
-                                                     poses_inv, group=_dist.exact_group())
+                                                     poses_inv, group=_dist.exact_group(), hint=hint)
         ctx.flags, ctx.n_ref, ctx.n_scales = flags, n_ref, n_scales
         ctx.save_for_backward(tgt_img, K, *rest, ws)
         return photo, geom

@@ -10,7 +10,8 @@ from scsfm_hip import _lib
 
 EXPECTED = {
     "scsfm_abi_version",
-    "scsfm_pair_ws_bytes", "scsfm_pair_bwd_scratch_bytes", "scsfm_pair_fwd_f32", "scsfm_pair_bwd_f32", "scsfm_pair_refinalize_f32",
+    "scsfm_pair_ws_bytes", "scsfm_pair_bwd_scratch_bytes", "scsfm_pair_fwd_f32", "scsfm_pair_bwd_f32", "scsfm_pair_refinalize_f32", "scsfm_pair_fwd_spec_f32",
+    "scsfm_pair_fwd_spec_f64",
     "scsfm_pair_fwd_f64", "scsfm_pair_bwd_f64", "scsfm_pair_refinalize_f64",
     "scsfm_pairs_fwd_f32", "scsfm_pairs_bwd_f32", "scsfm_pairs_fwd_f64", "scsfm_pairs_bwd_f64",
     "scsfm_smooth_multi_fwd_f32", "scsfm_smooth_multi_bwd_f32", "scsfm_smooth_multi_fwd_f64",

@@ -279,3 +279,33 @@ def test_rejected_arguments_raise(lib):
         capi.pair_fwd(lib, ti, ri, td.double(), rd, po, K, 0)
     with pytest.raises(ValueError):
         capi.make_flags(padding_mode="reflection")
+
+
+@pytest.mark.parametrize("hint,upstream", [((0.7, 1.3), (0.7, 1.3)),   # speculation holds
+                                           ((1.0, 0.5), (2.0, 1.0)),   # same ratio, different scale: holds
+                                           ((0.7, 1.3), (1.0, 0.5)),   # wrong hint: device-side fallback
+                                           (None, (0.7, 1.3))])        # plain forward
+def test_speculative_forward_fp64(lib, hint, upstream):
+    """scsfm_pair_fwd_spec: the backward's tiled pass run as the forward.  Whatever the hint, losses
+    and gradients must equal the oracle's."""
+    d = synth.make_batch(2, 72, 100, n_ref=2, seed=23, depth="smooth")
+    c = lambda x: x.double().contiguous()
+    ti, K = c(d["tgt_img"]), c(d["intrinsics"])
+    ris = [c(r) for r in d["ref_imgs"]]
+    tds, rds = [c(d["tgt_depth"][0])], [[c(r[0])] for r in d["ref_depths"]]
+    ps, pis = [c(p) for p in d["poses"]], [c(p) for p in d["poses_inv"]]
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    td, rd = [leaf(t) for t in tds], [[leaf(t) for t in r] for r in rds]
+    pp, pi = [leaf(p) for p in ps], [leaf(p) for p in pis]
+    po, go = O.photo_and_geometry_loss(ti, ris, K, td, rd, pp, pi, 1, 1, 1, 1, "zeros")
+    (upstream[0] * po + upstream[1] * go).backward()
+    photo, geom, outs, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=hint)
+    assert abs(float(photo) - float(po)) < 1e-12 and abs(float(geom) - float(go)) < 1e-12
+    g_td, g_rd, g_p, g_pi = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws,
+                                                    torch.tensor([upstream[0]], dtype=torch.float64),
+                                                    torch.tensor([upstream[1]], dtype=torch.float64))
+    z = lambda t: t.grad if t.grad is not None else torch.zeros_like(t)
+    assert _rel(g_td[0], z(td[0])) < 1e-10
+    for i in range(2):
+        assert _rel(g_rd[i][0], z(rd[i][0])) < 1e-10
+        assert _rel(g_p[i], z(pp[i])) < 1e-10 and _rel(g_pi[i], z(pi[i])) < 1e-10
