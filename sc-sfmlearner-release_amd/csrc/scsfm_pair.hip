@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
   T coef[STRIP];  // a * m * (1 - dd): weight of blend_c(q) in the loss
   T mq[STRIP];    // mask of the owned pixel
   T bsum[STRIP];  // sum_c blend_c of the owned pixel
-  T ddq[kSpec ? STRIP : 1];  // diff_depth of the owned pixel (forward sums)
+  T acc_g = T(0), acc_m = T(0);  // kSpec: forward sums over the pixels this block owns
   V2 cen[kSsim ? 1 : STRIP][kSsim ? 1 : 3];
   // ---- phase 1a ------------------------------------------------------------------------------
 #pragma unroll
@@ -271,7 +271,9 @@ __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
     mq[k] = inimg ? pixel_mask(s, with_auto, xy, ref_img, plane, unsigned(v) * unsigned(W) + unsigned(u)) : T(0);
     coef[k] = a * mq[k] * (with_mask ? (T(1) - ddk) : T(1));
     bsum[k] = T(0);
-    if constexpr (kSpec) ddq[k] = ddk;
+    if constexpr (kSpec) {
+      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) { acc_g += ddk * mq[k]; acc_m += mq[k]; }
+    }
   }
   // ---- phase 1b: ring ------------------------------------------------------------------------
   if constexpr (kSsim) {
@@ -343,15 +345,12 @@ __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
           bg * mq[k] - (with_mask ? a * mq[k] * bsum[k] : T(0));
   }
   if constexpr (kSpec) {  // the forward's three sums over the pixels this block owns
-    T v[3] = {T(0), T(0), T(0)};
+    T v[3] = {T(0), acc_g, acc_m};
 #pragma unroll
     for (int k = 0; k < STRIP; ++k) {
       const int ly = strip * STRIP + k, py = py0 + k;
-      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) {
-        v[0] += bsum[k] * (with_mask ? (T(1) - ddq[k]) : T(1)) * mq[k];
-        v[1] += ddq[k] * mq[k];
-        v[2] += mq[k];
-      }
+      // with a = 1, coef = m * (1 - dd) (or m): exactly the weight of blend in the photo sum
+      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) v[0] += bsum[k] * coef[k];
     }
     block_sum<3>(v, red);
     if (threadIdx.x == 0) {
