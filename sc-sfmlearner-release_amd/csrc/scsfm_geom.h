@@ -69,10 +69,8 @@ __device__ __forceinline__ void quat_bwd(T qx, T qy, T qz, const T* g, T* gq3) {
 // Per-batch constants.  One thread per batch element.
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void prep_kernel(int B, const T* __restrict__ pose, const T* __restrict__ K,
-                            BatchConsts<T>* __restrict__ out) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+__device__ __forceinline__ void prep_one(int b, const T* __restrict__ pose, const T* __restrict__ K,
+                                         BatchConsts<T>* __restrict__ out) {
   const T* k = K + 9 * b;
   // K^-1 by the adjugate, evaluated in fp64 and rounded once (the reference calls
   // torch.inverse, an LU factorisation; both agree to 1 ulp on camera matrices).
@@ -95,6 +93,13 @@ __global__ void prep_kernel(int B, const T* __restrict__ pose, const T* __restri
   }
   o.pad[0] = o.pad[1] = o.pad[2] = T(0);
   out[b] = o;
+}
+
+template <typename T>
+__global__ void prep_kernel(int B, const T* __restrict__ pose, const T* __restrict__ K,
+                            BatchConsts<T>* __restrict__ out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) prep_one(b, pose, K, out);
 }
 
 // dL/d(A|c) (12 numbers, fp64) of one batch element -> dL/dpose: gT = K^T gP, then the euler chain.
@@ -131,11 +136,11 @@ __global__ void pose_bwd_kernel(int B, const T* __restrict__ pose, const T* __re
 // written by pair_bwd_geom_kernel, then the pose chain.  `live` = the geometry pass ran (it skips
 // when both upstream coefficients are zero and then leaves the partials untouched).
 template <typename T>
-__global__ void pose_reduce_bwd_kernel(int nblk, const T* __restrict__ pose, const T* __restrict__ K,
-                                       const double* __restrict__ gPp, const double* __restrict__ sums,
-                                       const T* __restrict__ g_photo, const T* __restrict__ g_geom,
-                                       T* __restrict__ gpose) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void pose_reduce_one(int b, int nblk, const T* __restrict__ pose, const T* __restrict__ K,
+                                                const double* __restrict__ gPp, const double* __restrict__ sums,
+                                                const T* __restrict__ g_photo, const T* __restrict__ g_geom,
+                                                T* __restrict__ gpose) {
+  const int lane = threadIdx.x;
   const bool live = !(T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0));
   double g[12];
 #pragma unroll

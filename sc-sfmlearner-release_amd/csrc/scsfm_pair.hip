@@ -21,6 +21,22 @@
 
 namespace scsfm {
 
+// Device pointers of one pair-direction.  Kernels receive up to kMaxPairs of them by value (kernel
+// argument segment, read with scalar loads) and find theirs from blockIdx.z = pair * B + b, so that all
+// pair-directions of a training step (2 per reference frame and scale) run as ONE launch per stage:
+// 4x the blocks per launch (no half-empty last wave of blocks) and 4x fewer launches.
+template <typename T>
+struct PairArgs {
+  const T* tgt_img; const T* ref_img; const T* tgt_depth; const T* ref_depth; const T* pose;
+  BatchConsts<T>* consts; double* sums; double* partials; double* gPp;
+  T* out; T* gbuf; T* g_ref_depth; T* g_pose;
+};
+constexpr int kMaxPairs = 8;
+template <typename T>
+struct PairBatch {
+  PairArgs<T> p[kMaxPairs];
+};
+
 // Warp one pixel (already reflected into the image): the (target, warped) colour pairs.
 template <typename T>
 __device__ __forceinline__ Sample<T> warp_colours(const BatchConsts<T>& bc, int u, int v, int H, int W, unsigned flags,
@@ -35,6 +51,15 @@ __device__ __forceinline__ Sample<T> warp_colours(const BatchConsts<T>& bc, int 
     xy[c] = make2(tgt_img[c * plane + p], bilerp(t, s));
   }
   return s;
+}
+
+// prep_kernel over every (pair, batch element).
+template <typename T>
+__global__ void pairs_prep_kernel(PairBatch<T> pb, int n, int B, const T* __restrict__ K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * B) return;
+  const int pair = i / B, b = i - pair * B;
+  prep_one(b, pb.p[pair].pose, K, pb.p[pair].consts);
 }
 
 // Mask of an owned pixel: valid (inverse_warp.py:264), optionally AND auto-mask
@@ -58,16 +83,21 @@ __device__ __forceinline__ T pixel_mask(const Sample<T>& s, bool with_auto, cons
 // Forward
 // ==========================================================================================
 template <typename T, bool kSsim>
-__global__ __launch_bounds__(kThreads) void pair_fwd_kernel(
-    int H, int W, unsigned flags, const T* __restrict__ tgt_img, const T* __restrict__ ref_img,
-    const T* __restrict__ tgt_depth, const T* __restrict__ ref_depth, const BatchConsts<T>* __restrict__ consts,
-    double* __restrict__ partials) {
+__global__ __launch_bounds__(kThreads) void pair_fwd_kernel(PairBatch<T> pb, int B, int H, int W, unsigned flags) {
+  const int pair = blockIdx.z / B, b = blockIdx.z - pair * B;
+  const PairArgs<T>& pa = pb.p[pair];
+  const T* __restrict__ tgt_img = pa.tgt_img;
+  const T* __restrict__ ref_img = pa.ref_img;
+  const T* __restrict__ tgt_depth = pa.tgt_depth;
+  const T* __restrict__ ref_depth = pa.ref_depth;
+  const BatchConsts<T>* __restrict__ consts = pa.consts;
+  double* __restrict__ partials = pa.partials;
   typedef typename Vec2<T>::type V2;
   constexpr int TH = Tile<T>::kH, STRIP = TH / (kThreads / kWave);
   __shared__ V2 sXY[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];  // (target, warped) + 1-pixel ring
   __shared__ double red[3 * (kThreads / kWave)];
 
-  const int b = blockIdx.z, col = threadIdx.x & (kWave - 1), strip = threadIdx.x / kWave;
+  const int col = threadIdx.x & (kWave - 1), strip = threadIdx.x / kWave;
   const int tx0 = blockIdx.x * kTileW, ty0 = blockIdx.y * TH;
   const bool with_mask = (flags & SCSFM_WITH_MASK) != 0, with_auto = (flags & SCSFM_WITH_AUTO_MASK) != 0;
   const BatchConsts<T> bc = consts[b];
@@ -136,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(
   T v[3] = {acc_p, acc_g, acc_m};
   block_sum<3>(v, red);
   if (threadIdx.x == 0) {
-    double* o = partials + 3 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    double* o = partials + 3 * ((size_t)(b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
     o[0] = double(v[0]); o[1] = double(v[1]); o[2] = double(v[2]);
   }
 }
@@ -161,10 +191,13 @@ __device__ __forceinline__ void publish_losses(double Sp, double Sg, double Sm, 
 // One block: reduce the partials in fp64, apply the gates of mean_on_mask, publish the losses and
 // the coefficients the backward multiplies the upstream gradients with.
 template <typename T>
-__global__ __launch_bounds__(kThreads) void pair_finalize_kernel(int nblocks, const double* __restrict__ partials,
-                                                                 double* __restrict__ sums, T* __restrict__ out,
-                                                                 double spec, double w_photo, double w_geom) {
+__global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb, int nblocks, double spec,
+                                                                 double w_photo, double w_geom) {
   __shared__ double red[3 * (kThreads / kWave)];
+  const PairArgs<T>& pa = pb.p[blockIdx.x];
+  const double* __restrict__ partials = pa.partials;
+  double* __restrict__ sums = pa.sums;
+  T* __restrict__ out = pa.out;
   double v[3] = {0, 0, 0};
   for (int i = threadIdx.x; i < nblocks; i += kThreads) {
     v[0] += partials[3 * i]; v[1] += partials[3 * i + 1]; v[2] += partials[3 * i + 2];
@@ -213,10 +246,18 @@ __device__ __forceinline__ bool spec_valid(const double* __restrict__ sums, cons
 
 template <typename T, bool kSsim, bool kSpec>
 __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
-    int H, int W, unsigned flags, const T* __restrict__ tgt_img, const T* __restrict__ ref_img,
-    const T* __restrict__ tgt_depth, const T* __restrict__ ref_depth, const BatchConsts<T>* __restrict__ consts,
-    const double* __restrict__ sums, const T* __restrict__ g_photo, const T* __restrict__ g_geom,
-    T* __restrict__ gbuf, T r_hint, double* __restrict__ partials) {
+    PairBatch<T> pb, int B, int H, int W, unsigned flags, const T* __restrict__ g_photo,
+    const T* __restrict__ g_geom, T r_hint) {
+  const int pair = blockIdx.z / B, b = blockIdx.z - pair * B;
+  const PairArgs<T>& pa = pb.p[pair];
+  const T* __restrict__ tgt_img = pa.tgt_img;
+  const T* __restrict__ ref_img = pa.ref_img;
+  const T* __restrict__ tgt_depth = pa.tgt_depth;
+  const T* __restrict__ ref_depth = pa.ref_depth;
+  const BatchConsts<T>* __restrict__ consts = pa.consts;
+  const double* __restrict__ sums = pa.sums;
+  T* __restrict__ gbuf = pa.gbuf;
+  double* __restrict__ partials = pa.partials;
   typedef typename Vec2<T>::type V2;
   constexpr int TH = Tile<T>::kH, STRIP = TH / (kThreads / kWave);
   __shared__ V2 sXY[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];
@@ -232,13 +273,13 @@ __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
     if (spec_valid(sums, g_photo, g_geom)) return;  // the forward already left the planes in gbuf
   }
 
-  const int b = blockIdx.z, col = threadIdx.x & (kWave - 1), strip = threadIdx.x / kWave;
+  const int col = threadIdx.x & (kWave - 1), strip = threadIdx.x / kWave;
   // the 64 x TH compute domain starts one pixel before the 62 x (TH-2) block of outputs
   const int ox = blockIdx.x * (kTileW - 2) - 1, oy = blockIdx.y * (TH - 2) - 1;
   const bool with_mask = (flags & SCSFM_WITH_MASK) != 0, with_auto = (flags & SCSFM_WITH_AUTO_MASK) != 0;
   const BatchConsts<T> bc = consts[b];
   const unsigned plane = unsigned(H) * unsigned(W);
-  const size_t gplane = (size_t)gridDim.z * plane;  // one gbuf plane spans the whole batch
+  const size_t gplane = (size_t)B * plane;  // one gbuf plane spans the whole batch
   tgt_img += (size_t)b * 3 * plane;
   ref_img += (size_t)b * 3 * plane;
   tgt_depth += (size_t)b * plane;
@@ -354,7 +395,7 @@ __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
     }
     block_sum<3>(v, red);
     if (threadIdx.x == 0) {
-      double* o = partials + 3 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+      double* o = partials + 3 * ((size_t)(b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
       o[0] = double(v[0]); o[1] = double(v[1]); o[2] = double(v[2]);
     }
   }
@@ -368,10 +409,22 @@ __global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
 // ==========================================================================================
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
-    int H, int W, unsigned flags, const T* __restrict__ ref_img, const T* __restrict__ tgt_depth,
-    const T* __restrict__ ref_depth, const BatchConsts<T>* __restrict__ consts, const double* __restrict__ sums,
-    const T* __restrict__ g_photo, const T* __restrict__ g_geom, const T* __restrict__ gbuf,
-    T* __restrict__ g_tgt_depth, T* __restrict__ g_ref_depth, double* __restrict__ gP) {
+    PairBatch<T> pb, int B, int H, int W, unsigned flags, const T* __restrict__ g_photo,
+    const T* __restrict__ g_geom) {
+  const int pair = blockIdx.z / B, b = blockIdx.z - pair * B;
+  const PairArgs<T>& pa = pb.p[pair];
+  const T* __restrict__ ref_img = pa.ref_img;
+  const T* __restrict__ tgt_depth = pa.tgt_depth;
+  const T* __restrict__ ref_depth = pa.ref_depth;
+  const BatchConsts<T>* __restrict__ consts = pa.consts;
+  const double* __restrict__ sums = pa.sums;
+  const T* __restrict__ gbuf = pa.gbuf;
+  // dense dL/d tgt_depth goes to plane 4 of this pair's gbuf (a plain store); pairs_combine_kernel adds
+  // it to the caller's buffer afterwards.  That keeps every pair-direction of a step in one launch:
+  // the same depth map is the dense target of one pair and the scatter target of another.
+  T* __restrict__ g_tgt_depth = pa.gbuf + 4 * (size_t)B * H * W;
+  T* __restrict__ g_ref_depth = pa.g_ref_depth;
+  double* __restrict__ gP = pa.gPp;
   constexpr int ROWS = 4;  // pixels per thread: a block covers a 64 x 16 tile
   __shared__ double red[12 * (kThreads / kWave)];
   __shared__ T win[kWinH][kWinW];  // staging window of the scatter into dL/d ref_depth
@@ -379,12 +432,11 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
   if (T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0)) return;  // as in pass A
   // planes left by a speculative forward lack the common factor a = g_photo / (3 S_m)
   const T gscale = spec_valid(sums, g_photo, g_geom) ? T(sums[5]) * g_photo[0] : T(1);
-  const int b = blockIdx.z;
   const int px = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
   const int py0 = (blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave) * ROWS;
   const BatchConsts<T> bc = consts[b];
   const unsigned plane = unsigned(H) * unsigned(W);
-  const size_t gplane = (size_t)gridDim.z * plane;
+  const size_t gplane = (size_t)B * plane;
   ref_img += (size_t)b * 3 * plane;
   tgt_depth += (size_t)b * plane;
   ref_depth += (size_t)b * plane;
@@ -439,7 +491,7 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
     giy += gDp * dot4(t, sg.cy);
     if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window(win, wx0, wy0, g_ref_depth, s, gDp);
     const T gd = pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
-    if (!(flags & SCSFM_DEBUG_X2)) g_tgt_depth[p] += gd; else if (gd == T(12345)) g_tgt_depth[p] = gd;
+    g_tgt_depth[p] = (flags & SCSFM_DEBUG_X2) ? T(0) : gd;
   }
   __syncthreads();
   if (!(flags & SCSFM_DEBUG_X1)) flush_scatter_window(win, wx0, wy0, g_ref_depth, W);
@@ -456,94 +508,165 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
   }
 }
 
+// One wave per (pair, batch element): reduce the geometry pass's per-block partials, finish dL/dpose.
+template <typename T>
+__global__ void pairs_pose_reduce_kernel(PairBatch<T> pb, int B, int nblk, const T* __restrict__ K,
+                                         const T* __restrict__ g_photo, const T* __restrict__ g_geom) {
+  const int pair = blockIdx.x / B, b = blockIdx.x - pair * B;
+  const PairArgs<T>& pa = pb.p[pair];
+  pose_reduce_one(b, nblk, pa.pose, K, pa.gPp, pa.sums, g_photo, g_geom, pa.g_pose);
+}
+
+// dst[d] += sum of the dense planes of the pairs whose target depth map it is.  A pair whose geometry
+// pass skipped (both upstream coefficients zero) left its plane untouched and is skipped here too.
+template <typename T>
+struct CombineBatch {
+  T* dst[kMaxPairs];
+  int nsrc[kMaxPairs];
+  const T* src[kMaxPairs][kMaxPairs];
+  const double* sums[kMaxPairs][kMaxPairs];
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T> cb, size_t n,
+                                                                 const T* __restrict__ g_photo,
+                                                                 const T* __restrict__ g_geom) {
+  const int d = blockIdx.y;
+  T* __restrict__ dst = cb.dst[d];
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) {
+    T acc = T(0);
+    for (int k = 0; k < cb.nsrc[d]; ++k) {
+      const double* s = cb.sums[d][k];
+      if (!(T(s[5]) * g_photo[0] == T(0) && T(s[6]) * g_geom[0] == T(0))) acc += cb.src[d][k][i];
+    }
+    dst[i] += acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Host side of the C ABI.
 // ------------------------------------------------------------------------------------------
 template <typename T>
-static int pair_fwd(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth, const T* ref_depth,
-                    const T* pose, const T* K, unsigned flags, void* ws, T* out, void* stream_) {
-  clear_status();
-  if (B <= 0 || H < 2 || W < 2 || !tgt_img || !ref_img || !tgt_depth || !ref_depth || !pose || !K || !ws || !out)
-    return SCSFM_ERR_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
+static PairArgs<T> make_pair_args(const scsfm_pair_desc& d, int B, int H, int W, void* shared_scratch, int idx) {
   const PairWs l = pair_ws_layout(B, H, W);
-  char* base = reinterpret_cast<char*>(ws);
-  auto* consts = reinterpret_cast<BatchConsts<T>*>(base);
-  double* sums = reinterpret_cast<double*>(base + l.off_sums);
-  double* partials = reinterpret_cast<double*>(base + l.off_partials);
-  hipLaunchKernelGGL((prep_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, consts);
-  dim3 grid(ceil_div(W, kTileW), ceil_div(H, Tile<T>::kH), B);
-  if (flags & SCSFM_WITH_SSIM)
-    hipLaunchKernelGGL((pair_fwd_kernel<T, true>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img, ref_img,
-                       tgt_depth, ref_depth, (const BatchConsts<T>*)consts, partials);
-  else
-    hipLaunchKernelGGL((pair_fwd_kernel<T, false>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img, ref_img,
-                       tgt_depth, ref_depth, (const BatchConsts<T>*)consts, partials);
-  hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(1), dim3(kThreads), 0, stream, (int)(grid.x * grid.y * grid.z),
-                     (const double*)partials, sums, out, 0.0, 0.0, 0.0);
-  return launch_status();
+  char* base = reinterpret_cast<char*>(d.ws);
+  PairArgs<T> a;
+  a.tgt_img = (const T*)d.tgt_img; a.ref_img = (const T*)d.ref_img;
+  a.tgt_depth = (const T*)d.tgt_depth; a.ref_depth = (const T*)d.ref_depth; a.pose = (const T*)d.pose;
+  a.consts = reinterpret_cast<BatchConsts<T>*>(base);
+  a.sums = reinterpret_cast<double*>(base + l.off_sums);
+  a.partials = reinterpret_cast<double*>(base + l.off_partials);
+  a.gPp = reinterpret_cast<double*>(base + l.off_gP);
+  a.out = (T*)d.out;
+  a.gbuf = d.gbuf ? (T*)d.gbuf
+                  : (shared_scratch ? (T*)((char*)shared_scratch + (size_t)idx * scsfm_pair_bwd_scratch_bytes(B, H, W))
+                                    : (T*)nullptr);
+  a.g_ref_depth = (T*)d.g_ref_depth;
+  a.g_pose = (T*)d.g_pose;
+  return a;
 }
 
-// Forward that also leaves the backward's pass-A planes in `gbuf` (see pair_bwd_photo_kernel, kSpec).
+static bool desc_inputs_ok(const scsfm_pair_desc& d) {
+  return d.tgt_img && d.ref_img && d.tgt_depth && d.ref_depth && d.pose && d.ws;
+}
+
+// Forward of up to kMaxPairs pair-directions per launch.  `spec`: every pair has a gbuf and w_photo != 0.
 template <typename T>
-static int pair_fwd_spec(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth,
-                         const T* ref_depth, const T* pose, const T* K, unsigned flags, void* ws, void* gbuf,
-                         double w_photo, double w_geom, T* out, void* stream_) {
-  clear_status();
-  if (B <= 0 || H < 2 || W < 2 || !tgt_img || !ref_img || !tgt_depth || !ref_depth || !pose || !K || !ws || !out ||
-      !gbuf || w_photo == 0.0)
-    return SCSFM_ERR_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
-  const PairWs l = pair_ws_layout(B, H, W);
-  char* base = reinterpret_cast<char*>(ws);
-  auto* consts = reinterpret_cast<BatchConsts<T>*>(base);
-  double* sums = reinterpret_cast<double*>(base + l.off_sums);
-  double* partials = reinterpret_cast<double*>(base + l.off_partials);
-  hipLaunchKernelGGL((prep_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, consts);
-  dim3 grid(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), B);
-  const T r_hint = T(3.0 * w_geom / w_photo);
-  if (flags & SCSFM_WITH_SSIM)
-    hipLaunchKernelGGL((pair_bwd_photo_kernel<T, true, true>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img,
-                       ref_img, tgt_depth, ref_depth, (const BatchConsts<T>*)consts, (const double*)sums,
-                       (const T*)nullptr, (const T*)nullptr, reinterpret_cast<T*>(gbuf), r_hint, partials);
-  else
-    hipLaunchKernelGGL((pair_bwd_photo_kernel<T, false, true>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img,
-                       ref_img, tgt_depth, ref_depth, (const BatchConsts<T>*)consts, (const double*)sums,
-                       (const T*)nullptr, (const T*)nullptr, reinterpret_cast<T*>(gbuf), r_hint, partials);
-  hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(1), dim3(kThreads), 0, stream, (int)(grid.x * grid.y * grid.z),
-                     (const double*)partials, sums, out, 1.0, w_photo, w_geom);
+static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags, bool spec,
+                           double w_photo, double w_geom, hipStream_t stream) {
+  PairBatch<T> pb;
+  for (int i = 0; i < n; ++i) pb.p[i] = make_pair_args<T>(d[i], B, H, W, nullptr, i);
+  hipLaunchKernelGGL((pairs_prep_kernel<T>), dim3(ceil_div(n * B, 64)), dim3(64), 0, stream, pb, n, B, K);
+  dim3 grid;
+  if (spec) {
+    grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
+    const T r_hint = T(3.0 * w_geom / w_photo);
+    if (flags & SCSFM_WITH_SSIM)
+      hipLaunchKernelGGL((pair_bwd_photo_kernel<T, true, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags,
+                         (const T*)nullptr, (const T*)nullptr, r_hint);
+    else
+      hipLaunchKernelGGL((pair_bwd_photo_kernel<T, false, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags,
+                         (const T*)nullptr, (const T*)nullptr, r_hint);
+  } else {
+    grid = dim3(ceil_div(W, kTileW), ceil_div(H, Tile<T>::kH), n * B);
+    if (flags & SCSFM_WITH_SSIM)
+      hipLaunchKernelGGL((pair_fwd_kernel<T, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags);
+    else
+      hipLaunchKernelGGL((pair_fwd_kernel<T, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags);
+  }
+  hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(n), dim3(kThreads), 0, stream, pb, (int)(grid.x * grid.y * B),
+                     spec ? 1.0 : 0.0, spec ? w_photo : 0.0, spec ? w_geom : 0.0);
   return launch_status();
 }
 
 template <typename T>
-static int pair_bwd(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth, const T* ref_depth,
-                    const T* pose, const T* K, unsigned flags, void* ws, void* scratch, const T* g_photo,
-                    const T* g_geom, T* g_tgt_depth, T* g_ref_depth, T* g_pose, void* stream_) {
+static int pairs_fwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags, double w_photo,
+                     double w_geom, void* stream_) {
   clear_status();
-  if (B <= 0 || H < 2 || W < 2 || !tgt_img || !ref_img || !tgt_depth || !ref_depth || !pose || !K || !ws || !scratch ||
-      !g_photo || !g_geom || !g_tgt_depth || !g_ref_depth || !g_pose)
-    return SCSFM_ERR_ARG;
+  if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !K) return SCSFM_ERR_ARG;
+  for (int i = 0; i < n; ++i)
+    if (!desc_inputs_ok(d[i]) || !d[i].out) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
-  const PairWs l = pair_ws_layout(B, H, W);
-  char* base = reinterpret_cast<char*>(ws);
-  auto* consts = reinterpret_cast<const BatchConsts<T>*>(base);
-  const double* sums = reinterpret_cast<const double*>(base + l.off_sums);
-  double* gP = reinterpret_cast<double*>(base + l.off_gP);
-  T* gbuf = reinterpret_cast<T*>(scratch);
-  dim3 grid(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), B);
-  if (flags & SCSFM_DEBUG_SKIP_PHOTO) {
-  } else if (flags & SCSFM_WITH_SSIM)
-    hipLaunchKernelGGL((pair_bwd_photo_kernel<T, true, false>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img,
-                       ref_img, tgt_depth, ref_depth, consts, sums, g_photo, g_geom, gbuf, T(0), (double*)nullptr);
-  else
-    hipLaunchKernelGGL((pair_bwd_photo_kernel<T, false, false>), grid, dim3(kThreads), 0, stream, H, W, flags, tgt_img,
-                       ref_img, tgt_depth, ref_depth, consts, sums, g_photo, g_geom, gbuf, T(0), (double*)nullptr);
-  dim3 grid_b(ceil_div(W, kWave), ceil_div(H, 4 * (kThreads / kWave)), B);
-  if (!(flags & SCSFM_DEBUG_SKIP_GEOM))
-    hipLaunchKernelGGL((pair_bwd_geom_kernel<T>), grid_b, dim3(kThreads), 0, stream, H, W, flags, ref_img, tgt_depth,
-                     ref_depth, consts, sums, g_photo, g_geom, (const T*)gbuf, g_tgt_depth, g_ref_depth, gP);
-  hipLaunchKernelGGL((pose_reduce_bwd_kernel<T>), dim3(B), dim3(kWave), 0, stream, (int)(grid_b.x * grid_b.y), pose, K,
-                     (const double*)gP, sums, g_photo, g_geom, g_pose);
+  // maximal runs of descriptors with the same mode (speculative or plain), at most kMaxPairs each
+  int i = 0;
+  while (i < n) {
+    const bool spec = d[i].gbuf != nullptr && w_photo != 0.0;
+    int j = i + 1;
+    while (j < n && j - i < kMaxPairs && ((d[j].gbuf != nullptr && w_photo != 0.0) == spec)) ++j;
+    int rc = pairs_fwd_chunk<T>(j - i, d + i, B, H, W, K, flags, spec, w_photo, w_geom, stream);
+    if (rc) return rc;
+    i = j;
+  }
+  return SCSFM_OK;
+}
+
+template <typename T>
+static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags, void* scratch,
+                     const T* g_photo, const T* g_geom, void* stream_) {
+  clear_status();
+  if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !K || !g_photo || !g_geom) return SCSFM_ERR_ARG;
+  for (int i = 0; i < n; ++i)
+    if (!desc_inputs_ok(d[i]) || !d[i].g_tgt_depth || !d[i].g_ref_depth || !d[i].g_pose || (!d[i].gbuf && !scratch))
+      return SCSFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t npx = (size_t)B * H * W;
+  for (int i0 = 0; i0 < n; i0 += kMaxPairs) {
+    const int m = n - i0 < kMaxPairs ? n - i0 : kMaxPairs;
+    PairBatch<T> pb;
+    for (int i = 0; i < m; ++i) pb.p[i] = make_pair_args<T>(d[i0 + i], B, H, W, scratch, i0 + i);
+    if (!(flags & SCSFM_DEBUG_SKIP_PHOTO)) {
+      dim3 grid(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), m * B);
+      if (flags & SCSFM_WITH_SSIM)
+        hipLaunchKernelGGL((pair_bwd_photo_kernel<T, true, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags,
+                           g_photo, g_geom, T(0));
+      else
+        hipLaunchKernelGGL((pair_bwd_photo_kernel<T, false, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W,
+                           flags, g_photo, g_geom, T(0));
+    }
+    dim3 grid_b(ceil_div(W, kWave), ceil_div(H, 4 * (kThreads / kWave)), m * B);
+    if (!(flags & SCSFM_DEBUG_SKIP_GEOM))
+      hipLaunchKernelGGL((pair_bwd_geom_kernel<T>), grid_b, dim3(kThreads), 0, stream, pb, B, H, W, flags, g_photo,
+                         g_geom);
+    hipLaunchKernelGGL((pairs_pose_reduce_kernel<T>), dim3(m * B), dim3(kWave), 0, stream, pb, B,
+                       (int)(grid_b.x * grid_b.y), K, g_photo, g_geom);
+    if (!(flags & SCSFM_DEBUG_SKIP_GEOM)) {
+      // group the dense planes by the caller's destination buffer
+      CombineBatch<T> cb;
+      int nd = 0;
+      for (int i = 0; i < m; ++i) {
+        T* dst = (T*)d[i0 + i].g_tgt_depth;
+        int k = 0;
+        while (k < nd && cb.dst[k] != dst) ++k;
+        if (k == nd) { cb.dst[nd] = dst; cb.nsrc[nd] = 0; ++nd; }
+        cb.src[k][cb.nsrc[k]] = pb.p[i].gbuf + 4 * npx;
+        cb.sums[k][cb.nsrc[k]] = pb.p[i].sums;
+        ++cb.nsrc[k];
+      }
+      const int gx = (int)((npx + 4 * kThreads - 1) / (4 * kThreads));
+      hipLaunchKernelGGL((pairs_combine_kernel<T>), dim3(gx < 1 ? 1 : gx, nd), dim3(kThreads), 0, stream, cb, npx,
+                         g_photo, g_geom);
+    }
+  }
   return launch_status();
 }
 
@@ -557,13 +680,23 @@ static int pair_refinalize(int B, int H, int W, void* ws, T* out, void* stream) 
   return launch_status();
 }
 
+template <typename T>
+static scsfm_pair_desc one_desc(const T* tgt_img, const T* ref_img, const T* tgt_depth, const T* ref_depth,
+                                const T* pose, void* ws, void* out, void* g_tgt, void* g_ref, void* g_pose, void* gbuf) {
+  scsfm_pair_desc d;
+  d.tgt_img = tgt_img; d.ref_img = ref_img; d.tgt_depth = tgt_depth; d.ref_depth = ref_depth; d.pose = pose;
+  d.ws = ws; d.out = out; d.g_tgt_depth = g_tgt; d.g_ref_depth = g_ref; d.g_pose = g_pose; d.gbuf = gbuf;
+  return d;
+}
+
 }  // namespace scsfm
 
 extern "C" {
 
 size_t scsfm_pair_bwd_scratch_bytes(int B, int H, int W) {
   if (B <= 0 || H < 2 || W < 2) return 0;
-  return (size_t)4 * B * H * W * sizeof(double);  // four planes; sized for fp64 so one buffer serves both
+  // five planes per pair-direction (dL/dI_w x3, dL/d diff_depth, dense dL/d tgt_depth); sized for fp64
+  return (((size_t)5 * B * H * W * sizeof(double)) + 255) & ~(size_t)255;
 }
 
 size_t scsfm_pair_ws_bytes(int B, int H, int W) {
@@ -571,66 +704,40 @@ size_t scsfm_pair_ws_bytes(int B, int H, int W) {
   return scsfm::pair_ws_layout(B, H, W).total;  // sized for both precisions and both forward kernels
 }
 
-// Several pair-directions per call: one trip through the binding layer per step instead of one per
-// pair (the per-call host cost of a ctypes round trip, ~25 us, is comparable to a kernel here).
-#define SCSFM_PAIRS_API(SUF, T)                                                                                       \
+#define SCSFM_PAIR_API(SUF, T)                                                                                        \
   int scsfm_pairs_fwd_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,          \
                             double w_photo, double w_geom, void* stream) {                                            \
-    if (n < 0 || (n > 0 && !d)) return SCSFM_ERR_ARG;                                                                 \
-    for (int i = 0; i < n; ++i) {                                                                                     \
-      int rc = (d[i].gbuf && w_photo != 0.0)                                                                          \
-                   ? scsfm::pair_fwd_spec<T>(B, H, W, (const T*)d[i].tgt_img, (const T*)d[i].ref_img,                 \
-                                             (const T*)d[i].tgt_depth, (const T*)d[i].ref_depth, (const T*)d[i].pose, \
-                                             K, flags, d[i].ws, d[i].gbuf, w_photo, w_geom, (T*)d[i].out, stream)     \
-                   : scsfm::pair_fwd<T>(B, H, W, (const T*)d[i].tgt_img, (const T*)d[i].ref_img,                      \
-                                        (const T*)d[i].tgt_depth, (const T*)d[i].ref_depth, (const T*)d[i].pose, K,   \
-                                        flags, d[i].ws, (T*)d[i].out, stream);                                        \
-      if (rc) return rc;                                                                                              \
-    }                                                                                                                 \
-    return SCSFM_OK;                                                                                                  \
+    return scsfm::pairs_fwd<T>(n, d, B, H, W, K, flags, w_photo, w_geom, stream);                                     \
   }                                                                                                                   \
   int scsfm_pairs_bwd_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,          \
                             void* scratch, const T* g_photo, const T* g_geom, void* stream) {                         \
-    if (n < 0 || (n > 0 && !d)) return SCSFM_ERR_ARG;                                                                 \
-    for (int i = 0; i < n; ++i) {                                                                                     \
-      int rc = scsfm::pair_bwd<T>(B, H, W, (const T*)d[i].tgt_img, (const T*)d[i].ref_img, (const T*)d[i].tgt_depth,  \
-                                  (const T*)d[i].ref_depth, (const T*)d[i].pose, K, flags, d[i].ws,                   \
-                                  d[i].gbuf ? d[i].gbuf : scratch, g_photo, g_geom, (T*)d[i].g_tgt_depth,             \
-                                  (T*)d[i].g_ref_depth, (T*)d[i].g_pose, stream);                                     \
-      if (rc) return rc;                                                                                              \
-    }                                                                                                                 \
-    return SCSFM_OK;                                                                                                  \
-  }
-
-SCSFM_PAIRS_API(f32, float)
-SCSFM_PAIRS_API(f64, double)
-
-#define SCSFM_PAIR_API(SUF, T)                                                                                        \
-  int scsfm_pair_fwd_spec_##SUF(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth,          \
-                                const T* ref_depth, const T* pose, const T* K, unsigned flags, void* ws, void* gbuf,  \
-                                double w_photo, double w_geom, T* out, void* stream) {                                \
-    return scsfm::pair_fwd_spec<T>(B, H, W, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, ws, gbuf,         \
-                                   w_photo, w_geom, out, stream);                                                     \
+    return scsfm::pairs_bwd<T>(n, d, B, H, W, K, flags, scratch, g_photo, g_geom, stream);                            \
   }                                                                                                                   \
   int scsfm_pair_fwd_##SUF(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth,               \
                            const T* ref_depth, const T* pose, const T* K, unsigned flags, void* ws, T* out,           \
                            void* stream) {                                                                            \
-    return scsfm::pair_fwd<T>(B, H, W, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, ws, out, stream);      \
+    scsfm_pair_desc d = scsfm::one_desc<T>(tgt_img, ref_img, tgt_depth, ref_depth, pose, ws, out, 0, 0, 0, 0);         \
+    return scsfm::pairs_fwd<T>(1, &d, B, H, W, K, flags, 0.0, 0.0, stream);                                           \
+  }                                                                                                                   \
+  int scsfm_pair_fwd_spec_##SUF(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth,          \
+                                const T* ref_depth, const T* pose, const T* K, unsigned flags, void* ws, void* gbuf,  \
+                                double w_photo, double w_geom, T* out, void* stream) {                                \
+    if (!gbuf || w_photo == 0.0) return SCSFM_ERR_ARG;                                                                \
+    scsfm_pair_desc d = scsfm::one_desc<T>(tgt_img, ref_img, tgt_depth, ref_depth, pose, ws, out, 0, 0, 0, gbuf);      \
+    return scsfm::pairs_fwd<T>(1, &d, B, H, W, K, flags, w_photo, w_geom, stream);                                    \
   }                                                                                                                   \
   int scsfm_pair_bwd_##SUF(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth,               \
-                           const T* ref_depth, const T* pose, const T* K, unsigned flags, void* ws,                   \
-                           void* scratch, const T* g_photo, const T* g_geom, T* g_tgt_depth, T* g_ref_depth,          \
-                           T* g_pose, void* stream) {                                                                 \
-    return scsfm::pair_bwd<T>(B, H, W, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, ws, scratch, g_photo,  \
-                              g_geom, g_tgt_depth, g_ref_depth, g_pose, stream);                                      \
+                           const T* ref_depth, const T* pose, const T* K, unsigned flags, void* ws, void* scratch,    \
+                           const T* g_photo, const T* g_geom, T* g_tgt_depth, T* g_ref_depth, T* g_pose,              \
+                           void* stream) {                                                                            \
+    if (!scratch) return SCSFM_ERR_ARG;                                                                               \
+    scsfm_pair_desc d = scsfm::one_desc<T>(tgt_img, ref_img, tgt_depth, ref_depth, pose, ws, 0, g_tgt_depth,           \
+                                           g_ref_depth, g_pose, scratch);                                             \
+    return scsfm::pairs_bwd<T>(1, &d, B, H, W, K, flags, scratch, g_photo, g_geom, stream);                           \
+  }                                                                                                                   \
+  int scsfm_pair_refinalize_##SUF(int B, int H, int W, void* ws, T* out, void* stream) {                              \
+    return scsfm::pair_refinalize<T>(B, H, W, ws, out, stream);                                                       \
   }
-
-int scsfm_pair_refinalize_f32(int B, int H, int W, void* ws, float* out, void* stream) {
-  return scsfm::pair_refinalize<float>(B, H, W, ws, out, stream);
-}
-int scsfm_pair_refinalize_f64(int B, int H, int W, void* ws, double* out, void* stream) {
-  return scsfm::pair_refinalize<double>(B, H, W, ws, out, stream);
-}
 
 SCSFM_PAIR_API(f32, float)
 SCSFM_PAIR_API(f64, double)

@@ -1,16 +1,23 @@
-// Edge-aware smoothness of the mean-normalised depth, one frame (get_smooth_loss,
-// loss_functions.py:133-152):
+// Edge-aware smoothness of the mean-normalised depth (get_smooth_loss, loss_functions.py:133-152):
 //     d = D / (mean_HW(D) + 1e-7);  loss = mean(|dx d| * exp(-mean_c |dx I|)) + mean(|dy d| * exp(-mean_c |dy I|))
 // Because the per-image normaliser is positive, |dx d| = |dx D| / den, so one pass over D and I
 // yields, per image, sum(D) and the two weighted edge sums; the loss and the mean's contribution
 // to the gradient follow from those three numbers:
 //     loss   = sum_b L_b / den_b,        L_b = Sx_b / cnt_x + Sy_b / cnt_y
 //     dL/dD  = g * [ (1/den_b) * dL_b/dD(p)  -  L_b / (den_b^2 * H * W) ]
+//
+// All frames of compute_smooth_loss (target + every reference, loss_functions.py:154-159) run in one
+// launch per stage (blockIdx.z = frame * B + b).  A thread walks a 4-row column strip: the row below
+// is loaded once and becomes the next row's centre, the right neighbour comes from the next lane by
+// shuffle (lane 63 loads it), and every edge weight -- one exp each -- is evaluated exactly once in
+// the forward and once per direction in the backward (the left / upper edge of a pixel is the
+// previous lane's / row's right / lower edge).
 #include "scsfm_common.h"
 
 namespace scsfm {
 
 constexpr int kSmRows = 4;  // rows per thread
+constexpr int kMaxFrames = 8;
 
 struct SmoothWs {
   size_t off_img, off_partials, total;
@@ -27,63 +34,92 @@ inline SmoothWs smooth_ws_layout(int B, int H, int W) {
 }
 
 template <typename T>
-__device__ __forceinline__ T edge_weight(const T* __restrict__ img, long plane, long p, long q) {
-  const T g = (t_abs(img[p] - img[q]) + t_abs(img[plane + p] - img[plane + q]) +
-               t_abs(img[2 * plane + p] - img[2 * plane + q])) / T(3);
-  return t_exp(-g);
+struct SmoothFrame {
+  const T* depth; const T* img; double* per_img; double* partials; T* out; T* g_depth;
+};
+template <typename T>
+struct SmoothBatch {
+  SmoothFrame<T> f[kMaxFrames];
+};
+
+template <typename T>
+struct Px {  // depth and colours of one pixel
+  T d, c0, c1, c2;
+};
+template <typename T>
+__device__ __forceinline__ Px<T> load_px(const T* __restrict__ depth, const T* __restrict__ img, unsigned plane, unsigned p) {
+  Px<T> r;
+  r.d = depth[p]; r.c0 = img[p]; r.c1 = img[plane + p]; r.c2 = img[2 * plane + p];
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ Px<T> shfl_down_px(const Px<T>& v) {
+  Px<T> r;
+  r.d = __shfl_down(v.d, 1); r.c0 = __shfl_down(v.c0, 1); r.c1 = __shfl_down(v.c1, 1); r.c2 = __shfl_down(v.c2, 1);
+  return r;
+}
+// exp(-mean_c |I(p) - I(q)|), loss_functions.py:148-152
+template <typename T>
+__device__ __forceinline__ T edge_weight(const Px<T>& a, const Px<T>& b) {
+  return t_exp(-(t_abs(a.c0 - b.c0) + t_abs(a.c1 - b.c1) + t_abs(a.c2 - b.c2)) / T(3));
 }
 
 template <typename T>
-__global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(int H, int W, const T* __restrict__ depth,
-                                                              const T* __restrict__ img,
-                                                              double* __restrict__ partials) {
+__global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(SmoothBatch<T> sb, int B, int H, int W) {
   __shared__ double red[3 * (kThreads / kWave)];
-  const int b = blockIdx.z, x = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const int frame = blockIdx.z / B, b = blockIdx.z - frame * B;
+  const SmoothFrame<T>& fr = sb.f[frame];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int x = blockIdx.x * kWave + lane;
   const int y0 = (blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave) * kSmRows;
-  const long plane = (long)H * W;
-  depth += (long)b * plane;
-  img += (long)b * 3 * plane;
+  const unsigned plane = unsigned(H) * unsigned(W);
+  const T* __restrict__ depth = fr.depth + (size_t)b * plane;
+  const T* __restrict__ img = fr.img + (size_t)b * 3 * plane;
+  const bool in_x = x < W;
+  const int xc = in_x ? x : W - 1;
   T sd = T(0), sx = T(0), sy = T(0);
-  if (x < W) {
+  Px<T> cur = load_px(depth, img, plane, unsigned(y0 < H ? y0 : H - 1) * unsigned(W) + unsigned(xc));
 #pragma unroll
-    for (int r = 0; r < kSmRows; ++r) {
-      const int y = y0 + r;
-      if (y >= H) break;
-      const long p = (long)y * W + x;
-      const T d = depth[p];
-      sd += d;
-      if (x + 1 < W) sx += t_abs(d - depth[p + 1]) * edge_weight(img, plane, p, p + 1);
-      if (y + 1 < H) sy += t_abs(d - depth[p + W]) * edge_weight(img, plane, p, p + W);
+  for (int r = 0; r < kSmRows; ++r) {
+    const int y = y0 + r;
+    const unsigned p = unsigned(y < H ? y : H - 1) * unsigned(W) + unsigned(xc);
+    Px<T> right = shfl_down_px(cur);  // every lane takes part
+    if (lane == kWave - 1 && x + 1 < W) right = load_px(depth, img, plane, p + 1);
+    const Px<T> down = load_px(depth, img, plane, unsigned(y + 1 < H ? y + 1 : H - 1) * unsigned(W) + unsigned(xc));
+    if (in_x && y < H) {
+      sd += cur.d;
+      if (x + 1 < W) sx += t_abs(cur.d - right.d) * edge_weight(cur, right);
+      if (y + 1 < H) sy += t_abs(cur.d - down.d) * edge_weight(cur, down);
     }
+    cur = down;
   }
   T v[3] = {sd, sx, sy};
   block_sum<3>(v, red);
   if (threadIdx.x == 0) {
-    double* o = partials + 3 * ((long)(b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    double* o = fr.partials + 3 * ((size_t)(b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
     o[0] = double(v[0]); o[1] = double(v[1]); o[2] = double(v[2]);
   }
 }
 
-// One block; each wave reduces whole images (b = wave, wave + 4, ...) with shuffles only, then the
-// per-wave loss contributions meet in LDS.
+// One block per frame; each wave reduces whole images (b = wave, wave + 4, ...) with shuffles only,
+// then the per-wave loss contributions meet in LDS.
 template <typename T>
-__global__ __launch_bounds__(kThreads) void smooth_finalize_kernel(int B, int H, int W, int nblk,
-                                                                   const double* __restrict__ partials,
-                                                                   double* __restrict__ per_img, T* __restrict__ out) {
+__global__ __launch_bounds__(kThreads) void smooth_finalize_kernel(SmoothBatch<T> sb, int B, int H, int W, int nblk) {
   __shared__ double red[kThreads / kWave];
+  const SmoothFrame<T>& fr = sb.f[blockIdx.x];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const double cnt_x = (double)B * H * (W - 1), cnt_y = (double)B * (H - 1) * W;
   double loss = 0.0;
   for (int b = wave; b < B; b += kThreads / kWave) {
     double v0 = 0, v1 = 0, v2 = 0;
     for (int i = lane; i < nblk; i += kWave) {
-      const double* q = partials + 3 * ((size_t)b * nblk + i);
+      const double* q = fr.partials + 3 * ((size_t)b * nblk + i);
       v0 += q[0]; v1 += q[1]; v2 += q[2];
     }
     v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
     const double den = v0 / ((double)H * W) + 1e-7;  // mean_HW(D) + 1e-7, loss_functions.py:139-140
     const double L = v1 / cnt_x + v2 / cnt_y;
-    if (lane == 0) { per_img[2 * b] = den; per_img[2 * b + 1] = L; }
+    if (lane == 0) { fr.per_img[2 * b] = den; fr.per_img[2 * b + 1] = L; }
     loss += L / den;
   }
   if (lane == 0) red[wave] = loss;
@@ -91,67 +127,111 @@ __global__ __launch_bounds__(kThreads) void smooth_finalize_kernel(int B, int H,
   if (threadIdx.x == 0) {
     double t = 0;
     for (int w = 0; w < kThreads / kWave; ++w) t += red[w];
-    out[0] = T(t);
+    fr.out[0] = T(t);
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(int B, int H, int W, const T* __restrict__ depth,
-                                                              const T* __restrict__ img,
-                                                              const double* __restrict__ per_img,
-                                                              const T* __restrict__ g_loss, T* __restrict__ g_depth) {
-  const int b = blockIdx.z, x = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+__global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(SmoothBatch<T> sb, int B, int H, int W,
+                                                              const T* __restrict__ g_loss) {
+  const int frame = blockIdx.z / B, b = blockIdx.z - frame * B;
+  const SmoothFrame<T>& fr = sb.f[frame];
+  if (!fr.g_depth) return;  // this frame's gradient is not wanted (workgroup-uniform)
+  const int lane = threadIdx.x & (kWave - 1);
+  const int x = blockIdx.x * kWave + lane;
   const int y0 = (blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave) * kSmRows;
-  if (x >= W) return;
-  const long plane = (long)H * W;
-  depth += (long)b * plane;
-  img += (long)b * 3 * plane;
-  g_depth += (long)b * plane;
+  const unsigned plane = unsigned(H) * unsigned(W);
+  const T* __restrict__ depth = fr.depth + (size_t)b * plane;
+  const T* __restrict__ img = fr.img + (size_t)b * 3 * plane;
+  T* __restrict__ g_depth = fr.g_depth + (size_t)b * plane;
+  const bool in_x = x < W;
+  const int xc = in_x ? x : W - 1;
   const T g = g_loss[0];
-  const T iden = T(1.0 / per_img[2 * b]);
+  const T iden = T(1.0 / fr.per_img[2 * b]);
   const T icx = T(1.0 / ((double)B * H * (W - 1))), icy = T(1.0 / ((double)B * (H - 1) * W));
-  const T mean_term = T(per_img[2 * b + 1] / (per_img[2 * b] * per_img[2 * b] * (double)H * W));
+  const T mean_term = T(fr.per_img[2 * b + 1] / (fr.per_img[2 * b] * fr.per_img[2 * b] * (double)H * W));
+  Px<T> cur = load_px(depth, img, plane, unsigned(y0 < H ? y0 : H - 1) * unsigned(W) + unsigned(xc));
+  // lower edge of the row above the strip
+  T ty_prev = T(0);
+  if (y0 > 0 && y0 < H) {
+    const Px<T> up = load_px(depth, img, plane, unsigned(y0 - 1) * unsigned(W) + unsigned(xc));
+    ty_prev = t_sgn(up.d - cur.d) * edge_weight(up, cur) * icy;
+  }
 #pragma unroll
   for (int r = 0; r < kSmRows; ++r) {
     const int y = y0 + r;
-    if (y >= H) break;
-    const long p = (long)y * W + x;
-    const T d = depth[p];
-    T acc = T(0);
-    if (x + 1 < W) acc += t_sgn(d - depth[p + 1]) * edge_weight(img, plane, p, p + 1) * icx;
-    if (x > 0) acc -= t_sgn(depth[p - 1] - d) * edge_weight(img, plane, p - 1, p) * icx;
-    if (y + 1 < H) acc += t_sgn(d - depth[p + W]) * edge_weight(img, plane, p, p + W) * icy;
-    if (y > 0) acc -= t_sgn(depth[p - W] - d) * edge_weight(img, plane, p - W, p) * icy;
-    g_depth[p] += g * (acc * iden - mean_term);
+    const unsigned p = unsigned(y < H ? y : H - 1) * unsigned(W) + unsigned(xc);
+    Px<T> right = shfl_down_px(cur);
+    if (lane == kWave - 1 && x + 1 < W) right = load_px(depth, img, plane, p + 1);
+    const Px<T> down = load_px(depth, img, plane, unsigned(y + 1 < H ? y + 1 : H - 1) * unsigned(W) + unsigned(xc));
+    // d/dD(p) of |D(p) - D(q)| w(p,q) / cnt : +sgn for the first pixel of an edge, -sgn for the second
+    const T tx = (in_x && x + 1 < W) ? t_sgn(cur.d - right.d) * edge_weight(cur, right) * icx : T(0);
+    const T ty = (y + 1 < H) ? t_sgn(cur.d - down.d) * edge_weight(cur, down) * icy : T(0);
+    T tx_left = __shfl_up(tx, 1);
+    if (lane == 0) {
+      tx_left = T(0);
+      if (x > 0 && in_x && y < H) {
+        const Px<T> left = load_px(depth, img, plane, p - 1);
+        tx_left = t_sgn(left.d - cur.d) * edge_weight(left, cur) * icx;
+      }
+    }
+    if (in_x && y < H) g_depth[p] += g * ((tx - tx_left + ty - ty_prev) * iden - mean_term);
+    ty_prev = ty;
+    cur = down;
   }
 }
 
 template <typename T>
-static int smooth_fwd(int B, int H, int W, const T* depth, const T* img, void* ws, T* out, void* stream_) {
+static SmoothFrame<T> make_frame(int B, int H, int W, const void* depth, const void* img, void* ws, T* out, void* g_depth) {
+  const SmoothWs l = smooth_ws_layout(B, H, W);
+  SmoothFrame<T> f;
+  f.depth = (const T*)depth; f.img = (const T*)img;
+  f.per_img = reinterpret_cast<double*>((char*)ws + l.off_img);
+  f.partials = reinterpret_cast<double*>((char*)ws + l.off_partials);
+  f.out = out; f.g_depth = (T*)g_depth;
+  return f;
+}
+
+template <typename T>
+static int smooth_multi_fwd(int n, const void* const* depths, const void* const* imgs, int B, int H, int W, void* ws,
+                            T* out, void* stream_) {
   clear_status();
-  if (B <= 0 || H < 2 || W < 2 || !depth || !img || !ws || !out) return SCSFM_ERR_ARG;
+  if (n < 0 || B <= 0 || H < 2 || W < 2 || (n > 0 && (!depths || !imgs || !ws || !out))) return SCSFM_ERR_ARG;
+  for (int i = 0; i < n; ++i)
+    if (!depths[i] || !imgs[i]) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const SmoothWs l = smooth_ws_layout(B, H, W);
-  char* base = reinterpret_cast<char*>(ws);
-  double* per_img = reinterpret_cast<double*>(base + l.off_img);
-  double* partials = reinterpret_cast<double*>(base + l.off_partials);
-  hipLaunchKernelGGL((smooth_fwd_kernel<T>), dim3(l.nbx, l.nby, B), dim3(kThreads), 0, stream, H, W, depth, img,
-                     partials);
-  hipLaunchKernelGGL((smooth_finalize_kernel<T>), dim3(1), dim3(kThreads), 0, stream, B, H, W, l.nbx * l.nby,
-                     (const double*)partials, per_img, out);
+  for (int i0 = 0; i0 < n; i0 += kMaxFrames) {
+    const int m = n - i0 < kMaxFrames ? n - i0 : kMaxFrames;
+    SmoothBatch<T> sb;
+    for (int i = 0; i < m; ++i)
+      sb.f[i] = make_frame<T>(B, H, W, depths[i0 + i], imgs[i0 + i], (char*)ws + (size_t)(i0 + i) * l.total, out + i0 + i,
+                              nullptr);
+    hipLaunchKernelGGL((smooth_fwd_kernel<T>), dim3(l.nbx, l.nby, m * B), dim3(kThreads), 0, stream, sb, B, H, W);
+    hipLaunchKernelGGL((smooth_finalize_kernel<T>), dim3(m), dim3(kThreads), 0, stream, sb, B, H, W, l.nbx * l.nby);
+  }
   return launch_status();
 }
 
 template <typename T>
-static int smooth_bwd(int B, int H, int W, const T* depth, const T* img, void* ws, const T* g_loss, T* g_depth,
-                      void* stream_) {
+static int smooth_multi_bwd(int n, const void* const* depths, const void* const* imgs, int B, int H, int W, void* ws,
+                            const T* g_loss, void* const* g_depths, void* stream_) {
   clear_status();
-  if (B <= 0 || H < 2 || W < 2 || !depth || !img || !ws || !g_loss || !g_depth) return SCSFM_ERR_ARG;
+  if (n < 0 || B <= 0 || H < 2 || W < 2 || (n > 0 && (!depths || !imgs || !ws || !g_loss || !g_depths)))
+    return SCSFM_ERR_ARG;
+  for (int i = 0; i < n; ++i)
+    if (!depths[i] || !imgs[i]) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const SmoothWs l = smooth_ws_layout(B, H, W);
-  const double* per_img = reinterpret_cast<const double*>(reinterpret_cast<char*>(ws) + l.off_img);
-  hipLaunchKernelGGL((smooth_bwd_kernel<T>), dim3(l.nbx, l.nby, B), dim3(kThreads), 0, stream, B, H, W, depth, img,
-                     per_img, g_loss, g_depth);
+  for (int i0 = 0; i0 < n; i0 += kMaxFrames) {
+    const int m = n - i0 < kMaxFrames ? n - i0 : kMaxFrames;
+    SmoothBatch<T> sb;
+    for (int i = 0; i < m; ++i)
+      sb.f[i] = make_frame<T>(B, H, W, depths[i0 + i], imgs[i0 + i], (char*)ws + (size_t)(i0 + i) * l.total, nullptr,
+                              g_depths[i0 + i]);
+    hipLaunchKernelGGL((smooth_bwd_kernel<T>), dim3(l.nbx, l.nby, m * B), dim3(kThreads), 0, stream, sb, B, H, W,
+                       g_loss);
+  }
   return launch_status();
 }
 
@@ -165,41 +245,25 @@ size_t scsfm_smooth_ws_bytes(int B, int H, int W) {
 }
 
 #define SCSFM_SMOOTH_API(SUF, T)                                                                                     \
-  int scsfm_smooth_fwd_##SUF(int B, int H, int W, const T* depth, const T* img, void* ws, T* out, void* stream) {    \
-    return scsfm::smooth_fwd<T>(B, H, W, depth, img, ws, out, stream);                                               \
-  }                                                                                                                  \
-  int scsfm_smooth_bwd_##SUF(int B, int H, int W, const T* depth, const T* img, void* ws, const T* g_loss,           \
-                             T* g_depth, void* stream) {                                                             \
-    return scsfm::smooth_bwd<T>(B, H, W, depth, img, ws, g_loss, g_depth, stream);                                   \
-  }
-
-#define SCSFM_SMOOTH_MULTI_API(SUF, T)                                                                               \
   int scsfm_smooth_multi_fwd_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,   \
                                    void* ws, T* out, void* stream) {                                                 \
-    if (n < 0 || (n > 0 && (!depths || !imgs || !ws || !out))) return SCSFM_ERR_ARG;                                 \
-    const size_t stride = scsfm::smooth_ws_layout(B, H, W).total;                                                    \
-    for (int i = 0; i < n; ++i) {                                                                                    \
-      int rc = scsfm::smooth_fwd<T>(B, H, W, (const T*)depths[i], (const T*)imgs[i], (char*)ws + i * stride,         \
-                                    out + i, stream);                                                                \
-      if (rc) return rc;                                                                                             \
-    }                                                                                                                \
-    return SCSFM_OK;                                                                                                 \
+    return scsfm::smooth_multi_fwd<T>(n, depths, imgs, B, H, W, ws, out, stream);                                    \
   }                                                                                                                  \
   int scsfm_smooth_multi_bwd_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,   \
                                    void* ws, const T* g_loss, void* const* g_depths, void* stream) {                 \
-    if (n < 0 || (n > 0 && (!depths || !imgs || !ws || !g_loss || !g_depths))) return SCSFM_ERR_ARG;                 \
-    const size_t stride = scsfm::smooth_ws_layout(B, H, W).total;                                                    \
-    for (int i = 0; i < n; ++i) {                                                                                    \
-      if (!g_depths[i]) continue;                                                                                    \
-      int rc = scsfm::smooth_bwd<T>(B, H, W, (const T*)depths[i], (const T*)imgs[i], (char*)ws + i * stride, g_loss, \
-                                    (T*)g_depths[i], stream);                                                        \
-      if (rc) return rc;                                                                                             \
-    }                                                                                                                \
-    return SCSFM_OK;                                                                                                 \
+    return scsfm::smooth_multi_bwd<T>(n, depths, imgs, B, H, W, ws, g_loss, g_depths, stream);                       \
+  }                                                                                                                  \
+  int scsfm_smooth_fwd_##SUF(int B, int H, int W, const T* depth, const T* img, void* ws, T* out, void* stream) {    \
+    const void* d = depth; const void* im = img;                                                                     \
+    if (!depth || !img) return SCSFM_ERR_ARG;                                                                        \
+    return scsfm::smooth_multi_fwd<T>(1, &d, &im, B, H, W, ws, out, stream);                                         \
+  }                                                                                                                  \
+  int scsfm_smooth_bwd_##SUF(int B, int H, int W, const T* depth, const T* img, void* ws, const T* g_loss,           \
+                             T* g_depth, void* stream) {                                                             \
+    const void* d = depth; const void* im = img; void* g = g_depth;                                                  \
+    if (!depth || !img || !g_depth) return SCSFM_ERR_ARG;                                                            \
+    return scsfm::smooth_multi_bwd<T>(1, &d, &im, B, H, W, ws, g_loss, &g, stream);                                  \
   }
-
-SCSFM_SMOOTH_MULTI_API(f32, float)
-SCSFM_SMOOTH_MULTI_API(f64, double)
 
 SCSFM_SMOOTH_API(f32, float)
 SCSFM_SMOOTH_API(f64, double)

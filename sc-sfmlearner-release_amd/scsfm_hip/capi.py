@@ -317,7 +317,9 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
     g_td = [torch.zeros_like(t) for t in tgt_depths]
     g_rd = [[torch.zeros_like(t) for t in r] for r in ref_depths]
     g_pose_all = torch.empty(n, B, 6, dtype=tgt_img.dtype, device=tgt_img.device)
-    scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=tgt_img.device)
+    # one private scratch region per pair (they run concurrently); the speculative forward already
+    # placed it behind each pair's workspace
+    scratch = None if spec else torch.empty(n * scratch_bytes, dtype=torch.uint8, device=tgt_img.device)
 
     def gbuf(key):
         return g_td[key[1]] if key[0] == "t" else g_rd[key[1]][key[2]]
