@@ -13,9 +13,10 @@ zeros padding, 1 scale; inputs are resident in HBM before the timed region.  Dat
 shard by batch (weak scaling, 12 samples per GPU) with no collective on the loss path.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (pair_bwd_kernel): algorithmic bytes per launch (48 B/pixel x
-                  B*H*W) / its average launch duration measured here with HIP events on
-                  the launching stream, against the 8 TB/s HBM3E peak
+  roofline     -- the dominant kernel (pair_bwd_photo_kernel as speculative forward, all pair-directions in
+                  one launch): algorithmic bytes per launch (48 B/pixel x B*H*W x pair-directions) / its
+                  average launch duration measured here with HIP events on the launching stream, against
+                  the 8 TB/s HBM3E peak
   cpu_baseline -- the CPU oracle (restatement of the reference's loss path on the same ATen CPU ops)
                   timed on this host's cores on a bounded sample (cfg0: batch 4), rank 0, N=1 only
 """
@@ -84,42 +85,82 @@ def _event_time(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e-3  # seconds per call
 
 
-def time_kernels(x, flags, iters):
-    """Average duration (HIP events on the launching stream = torch's current stream) of the C-ABI
-    entry points of one pair-direction and one smooth-loss frame.  The two backward kernels are also
-    timed alone through the ABI's debug stage mask; those figures still contain the ~5 us
-    pose_bwd_kernel launch that follows them, i.e. they over- rather than under-state the kernel."""
+def time_kernels(x, flags, iters, n_ref):
+    """Average duration (HIP events on the launching stream = torch's current stream) of the library
+    calls a step is made of, at the step's real launch shapes: the speculative forward of all
+    2*n_ref pair-directions (one pairs_prep + ONE pair_bwd_photo_kernel<.,.,spec> launch + one finalize),
+    their backward (geometry pass + pose reduce + combine, one launch each), and the smooth loss of the
+    1+n_ref frames.  The figure of a stage contains its few-microsecond helper kernels, i.e. it over-
+    rather than under-states the dominant kernel."""
     from scsfm_hip import _lib, capi
     lib = _lib.get()
     fl = capi.make_flags(*flags)
-    a = (x["tgt_img"], x["ref_imgs"][0], x["tgt_depth"][0].detach(), x["ref_depths"][0][0].detach(),
-         x["poses"][0].detach(), x["K"])
-    B, _, H, W = a[0].shape
-    out, ws = capi.pair_fwd(lib, *a, fl)
-    one = torch.ones(1, device=a[0].device)
-    g_t, g_r = torch.zeros_like(a[2]), torch.zeros_like(a[3])
-    scratch = capi.pair_bwd_scratch(lib, a[0], B, H, W)
-    dep, img = x["tgt_depth"][0].detach(), x["tgt_img"]
-    so, sws = capi.smooth_fwd(lib, dep, img)
-    SKIP_PHOTO, SKIP_GEOM = 256, 512
+    det = lambda t: t.detach()
+    tgt, K, refs = x["tgt_img"], x["K"], x["ref_imgs"]
+    tds, rds = [det(x["tgt_depth"][0])], [[det(r[0])] for r in x["ref_depths"]]
+    ps, pis = [det(p) for p in x["poses"]], [det(p) for p in x["poses_inv"]]
+    one, half = torch.ones(1, device=tgt.device), torch.full((1,), 0.5, device=tgt.device)
+    hint = (W_PHOTO, W_GEOM)
+    _, _, _, ws_spec = capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, hint=hint)
+    _, _, _, ws_plain = capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, hint=None)
+    frames, imgs = tds + [r[0] for r in rds], [tgt] + list(refs)
+    _, sws = capi.smooth_multi_fwd(lib, frames, imgs)
     calls = {
-        "pair_fwd": lambda: capi.pair_fwd_into(lib, *a, fl, out),
-        "pair_bwd": lambda: capi.pair_bwd(lib, *a, fl, ws, one, one, g_t, g_r, scratch),
-        "pair_bwd_photo_only": lambda: capi.pair_bwd(lib, *a, fl | SKIP_GEOM, ws, one, one, g_t, g_r, scratch),
-        "pair_bwd_geom_only": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO, ws, one, one, g_t, g_r, scratch),
-        "pair_fwd_spec": lambda: lib.call("scsfm_pair_fwd_spec_f32", B, H, W, *[t.data_ptr() for t in a], fl,
-                                          ws.data_ptr(), scratch.data_ptr(), 1.0, 0.5, out.data_ptr(),
-                                          torch.cuda.current_stream().cuda_stream),
-        "geom_noscatter": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | 1024, ws, one, one, g_t, g_r, scratch),
-        "geom_nodense": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | 2048, ws, one, one, g_t, g_r, scratch),
-        "geom_noreduce": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | 4096, ws, one, one, g_t, g_r, scratch),
-        "geom_nocolour": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | 8192, ws, one, one, g_t, g_r, scratch),
-        "geom_none": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | 1024 | 2048 | 4096 | 8192, ws, one, one, g_t, g_r, scratch),
-        "bwd_empty": lambda: capi.pair_bwd(lib, *a, fl | SKIP_PHOTO | SKIP_GEOM, ws, one, one, g_t, g_r, scratch),
-        "smooth_fwd": lambda: capi.smooth_fwd(lib, dep, img, so),
-        "smooth_bwd": lambda: capi.smooth_bwd(lib, dep, img, sws, one, g_t),
+        "pairs_fwd_spec": lambda: capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, hint=hint),
+        "pairs_fwd_plain": lambda: capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, hint=None),
+        "pairs_bwd_after_spec": lambda: capi.photo_geometry_bwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, ws_spec, one, half),
+        "pairs_bwd_after_plain": lambda: capi.photo_geometry_bwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, ws_plain, one, half),
+        "smooth_fwd": lambda: capi.smooth_multi_fwd(lib, frames, imgs),
+        "smooth_bwd": lambda: capi.smooth_multi_bwd(lib, frames, imgs, sws, one),
     }
     return {k: _event_time(fn, iters) for k, fn in calls.items()}
+
+
+def e2e_train(args, device, world, local_rank, barrier):
+    """Whole training step of BASELINE.json's metric (train.py:249-286): 3 DispResNet18 + 4 PoseResNet18
+    forwards (PyTorch-ROCm / MIOpen), the HIP loss path, backward, Adam; data parallel with
+    DistributedDataParallel over RCCL when world > 1.  Synthetic batch resident in HBM, random-init nets."""
+    import argparse as _ap
+
+    import models
+    import train as T
+    torch.manual_seed(0)
+    targs = _ap.Namespace(photo_loss_weight=W_PHOTO, smooth_loss_weight=W_SMOOTH, geometry_consistency_weight=W_GEOM,
+                          num_scales=1, with_ssim=1, with_mask=1, with_auto_mask=1, padding_mode="zeros", world=world,
+                          exact_mask_normalisation=False)
+    disp_net = models.DispResNet(18, False).to(device).train()
+    pose_net = models.PoseResNet(18, False).to(device).train()
+    if world > 1:
+        ddp = torch.nn.parallel.DistributedDataParallel
+        disp_net = ddp(disp_net, device_ids=[local_rank], bucket_cap_mb=64, gradient_as_bucket_view=True)
+        pose_net = ddp(pose_net, device_ids=[local_rank], bucket_cap_mb=64, gradient_as_bucket_view=True)
+    params = [{"params": [p for p in disp_net.parameters() if p.requires_grad]},
+              {"params": [p for p in pose_net.parameters() if p.requires_grad]}]
+    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999))
+    g = torch.Generator().manual_seed(1234 + local_rank)
+    mk = lambda: ((torch.rand(args.batch, 3, args.height, args.width, generator=g) - 0.45) / 0.225).to(device)
+    tgt, refs = mk(), [mk() for _ in range(args.n_ref)]
+    from scsfm_hip import synth
+    K = synth.intrinsics(__import__("numpy").random.default_rng(local_rank), args.batch, args.height, args.width,
+                         args.dataset).to(device)
+    for _ in range(args.e2e_warmup):
+        T.train_step(targs, disp_net, pose_net, opt, tgt, refs, K)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.e2e_steps):
+        loss = T.train_step(targs, disp_net, pose_net, opt, tgt, refs, K)[0]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return {"train_images_per_sec": round(world * args.batch * args.e2e_steps / dt, 2),
+            "ms_per_step": round(dt / args.e2e_steps * 1e3, 3), "steps": args.e2e_steps, "warmup": args.e2e_warmup,
+            "model": "DispResNet18 + PoseResNet18, random init, fp32", "global_batch": world * args.batch,
+            "parallelism": f"ddp{world} (RCCL all-reduce of 26.8 M fp32 gradients per step)" if world > 1 else "1 GPU",
+            "final_loss": float(loss.detach())}
 
 
 def cpu_baseline(args, flags, budget_s):
@@ -182,6 +223,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on the CPU baseline's intra-op threads")
     ap.add_argument("--kernel-iters", type=int, default=30)
+    ap.add_argument("--e2e-steps", type=int, default=20, help="timed whole-training steps with the nets (0 = skip)")
+    ap.add_argument("--e2e-warmup", type=int, default=5)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -232,22 +275,30 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
 
-    kt = time_kernels(x, flags, args.kernel_iters)
-    # dominant kernel: the tiled backward pass.  Algorithmic bytes per launch: it must read both images
-    # and both depth maps once (32 B/px) and write dL/d(warped colours, diff_depth) once (16 B/px).
-    photo_bytes = 48 * n_px
-    achieved = photo_bytes / kt["pair_bwd_photo_only"] / 1e9
-    roofline = {"bound": "hbm", "kernel": "pair_bwd_photo_kernel<float,true>", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "algorithmic_bytes_per_launch": photo_bytes,
-                "avg_launch_us": round(kt["pair_bwd_photo_only"] * 1e6, 2)}
-    # SURVEY.md 8d figure for a whole pair-direction (forward + backward): 48 B/px
-    pair_t = kt["pair_fwd"] + kt["pair_bwd"]
+    kt = time_kernels(x, flags, args.kernel_iters, args.n_ref)
+    n_pairs = 2 * args.n_ref
+    # dominant kernel: pair_bwd_photo_kernel in its speculative-forward form, all pair-directions in one
+    # launch.  Algorithmic bytes per launch: per pair-direction it must read both images and both depth
+    # maps once (32 B/px) and write dL/d(warped colours, diff_depth) once (16 B/px).
+    spec_bytes = n_pairs * 48 * n_px
+    achieved = spec_bytes / kt["pairs_fwd_spec"] / 1e9
+    roofline = {"bound": "hbm", "kernel": f"pair_bwd_photo_kernel<float,true,true> ({n_pairs} pair-directions per launch)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": spec_bytes, "avg_launch_us": round(kt["pairs_fwd_spec"] * 1e6, 2)}
+    # SURVEY.md 8d figure: one pair-direction forward + backward = 48 B/px
+    pair_t = (kt["pairs_fwd_spec"] + kt["pairs_bwd_after_spec"]) / n_pairs
     pair_roofline = {"algorithmic_bytes": 48 * n_px, "us": round(pair_t * 1e6, 2),
                      "achieved_GBs": round(48 * n_px / pair_t / 1e9, 1),
                      "frac": round(48 * n_px / pair_t / 1e9 / HBM_PEAK_GBS, 4)}
-    # sum of the kernel launches of one step, from the per-entry-point event timings
-    kernel_sum = args.n_ref * 2 * (kt["pair_fwd"] + kt["pair_bwd"]) + (1 + args.n_ref) * (kt["smooth_fwd"] + kt["smooth_bwd"])
+    kernel_sum = kt["pairs_fwd_spec"] + kt["pairs_bwd_after_spec"] + kt["smooth_fwd"] + kt["smooth_bwd"]
+
+    e2e = None
+    if args.e2e_steps > 0:
+        try:
+            e2e = e2e_train(args, device, world, local_rank, barrier)
+        except Exception as exc:  # the hot-path figures above stay valid; say what happened
+            e2e = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         res = {
@@ -268,6 +319,7 @@ def main():
             "losses": {"total": loss, "photo": photo, "smooth": smooth, "geometry": geom},
             "roofline": roofline,
             "pair_direction_roofline": pair_roofline,
+            "e2e_train": e2e,
         }
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(args, flags, args.cpu_seconds)

@@ -314,8 +314,11 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
     ws_bytes, scratch_bytes, _ = _sizes(lib, B, H, W)
     spec = ws.numel() == n * (ws_bytes + scratch_bytes)  # the forward was speculative: gbuf follows each workspace
     stride = ws_bytes + (scratch_bytes if spec else 0)
-    g_td = [torch.zeros_like(t) for t in tgt_depths]
-    g_rd = [[torch.zeros_like(t) for t in r] for r in ref_depths]
+    # one zero-fill for every depth-gradient buffer (they all have the full-resolution shape)
+    n_maps = len(tgt_depths) * (1 + len(ref_depths))
+    g_all = torch.zeros((n_maps,) + tuple(tgt_depths[0].shape), dtype=tgt_img.dtype, device=tgt_img.device)
+    g_td = [g_all[s] for s in range(len(tgt_depths))]
+    g_rd = [[g_all[len(tgt_depths) * (1 + i) + s] for s in range(len(tgt_depths))] for i in range(len(ref_depths))]
     g_pose_all = torch.empty(n, B, 6, dtype=tgt_img.dtype, device=tgt_img.device)
     # one private scratch region per pair (they run concurrently); the speculative forward already
     # placed it behind each pair's workspace
@@ -370,7 +373,8 @@ def smooth_multi_bwd(lib, depths, imgs, ws, g_loss, need=None):
     """-> list of dL/d depth (None where ``need[i]`` is False)."""
     B, _, H, W = imgs[0].shape
     n = len(depths)
-    grads = [torch.zeros_like(d) if (need is None or need[i]) else None for i, d in enumerate(depths)]
+    g_all = torch.zeros((n,) + tuple(depths[0].shape), dtype=depths[0].dtype, device=depths[0].device)
+    grads = [g_all[i] if (need is None or need[i]) else None for i in range(n)]
     lib.call(f"scsfm_smooth_multi_bwd_{_suffix(imgs[0])}", n, _ptr_array(depths), _ptr_array(imgs), B, H, W, _p(ws),
              _p(g_loss), _ptr_array(grads), _stream(imgs[0]))
     return grads

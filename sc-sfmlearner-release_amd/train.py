@@ -1,0 +1,374 @@
+"""SC-SfMLearner training, MI355X-native: the reference's command line (train.py:24-61) and checkpoint
+format, the HIP loss path (loss_functions.py / inverse_warp.py of this directory), DispResNet /
+PoseResNet on PyTorch-ROCm (MIOpen), and pure data parallelism with one process per GPU:
+
+    python train.py DATA --resnet-layers 18 --num-scales 1 -b12 -s0.1 -c0.5 --sequence-length 3 \
+        --with-ssim 1 --with-mask 1 --with-auto-mask 1 --with-pretrain 0 --name r18            # 1 GPU
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py DATA ... -b12       # 8 GPUs
+
+Differences from the reference, all forced by the platform or by the scale-out design:
+  * `nn.DataParallel` (train.py:168-169: one process, loss on GPU 0 over the gathered batch) becomes
+    `DistributedDataParallel` over RCCL; `-b` is the PER-GPU batch (global = world x b); the loss is
+    computed on each rank's shard.  `--exact-mask-normalisation` (extension) all-reduces the mask sums
+    so that the loss equals the single-process loss on the global batch.
+  * `--with-pretrain 1` needs ImageNet weights from the network -> rejected offline; use
+    `--pretrained-disp/--pretrained-pose`.
+  * DATA may be `synthetic:N:HxW` (extension): N in-memory random sequences, for smoke / throughput runs.
+  * tensorboardX / blessings / progressbar2 / path are not installed: scalars go to the two TSV logs
+    (same files and columns as the reference) and to stdout.
+  * `torch.autograd.set_detect_anomaly(True)` (train.py:67) is not enabled: the kernels are NaN-free.
+"""
+import argparse
+import csv
+import datetime
+import os
+import time
+
+import numpy as np
+import torch
+import torch.optim
+import torch.utils.data
+
+import custom_transforms
+import models
+from logger import AverageMeter, TermLogger
+from loss_functions import compute_errors, compute_photo_and_geometry_loss, compute_smooth_loss
+from scsfm_hip import config as hip_config
+from scsfm_hip import dist as hip_dist
+from utils import save_checkpoint
+
+parser = argparse.ArgumentParser(description='Structure from Motion Learner training on KITTI and CityScapes Dataset',
+                                 formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+parser.add_argument('data', metavar='DIR', help='path to dataset')
+parser.add_argument('--folder-type', type=str, choices=['sequence', 'pair'], default='sequence', help='the dataset dype to train')
+parser.add_argument('--sequence-length', type=int, metavar='N', help='sequence length for training', default=3)
+parser.add_argument('-j', '--workers', default=4, type=int, metavar='N', help='number of data loading workers')
+parser.add_argument('--epochs', default=200, type=int, metavar='N', help='number of total epochs to run')
+parser.add_argument('--epoch-size', default=0, type=int, metavar='N', help='manual epoch size (will match dataset size if not set)')
+parser.add_argument('-b', '--batch-size', default=4, type=int, metavar='N', help='mini-batch size (per GPU)')
+parser.add_argument('--lr', '--learning-rate', default=1e-4, type=float, metavar='LR', help='initial learning rate')
+parser.add_argument('--momentum', default=0.9, type=float, metavar='M', help='momentum for sgd, alpha parameter for adam')
+parser.add_argument('--beta', default=0.999, type=float, metavar='M', help='beta parameters for adam')
+parser.add_argument('--weight-decay', '--wd', default=0, type=float, metavar='W', help='weight decay')
+parser.add_argument('--print-freq', default=10, type=int, metavar='N', help='print frequency')
+parser.add_argument('--seed', default=0, type=int, help='seed for random functions, and network initialization')
+parser.add_argument('--log-summary', default='progress_log_summary.csv', metavar='PATH', help='csv where to save per-epoch train and valid stats')
+parser.add_argument('--log-full', default='progress_log_full.csv', metavar='PATH', help='csv where to save per-gradient descent train stats')
+parser.add_argument('--log-output', action='store_true', help='will log dispnet outputs at validation step')
+parser.add_argument('--resnet-layers', type=int, default=18, choices=[18, 50], help='number of ResNet layers for depth estimation.')
+parser.add_argument('--num-scales', '--number-of-scales', type=int, help='the number of scales', metavar='W', default=1)
+parser.add_argument('-p', '--photo-loss-weight', type=float, help='weight for photometric loss', metavar='W', default=1)
+parser.add_argument('-s', '--smooth-loss-weight', type=float, help='weight for disparity smoothness loss', metavar='W', default=0.1)
+parser.add_argument('-c', '--geometry-consistency-weight', type=float, help='weight for depth consistency loss', metavar='W', default=0.5)
+parser.add_argument('--with-ssim', type=int, default=1, help='with ssim or not')
+parser.add_argument('--with-mask', type=int, default=1, help='with the the mask for moving objects and occlusions or not')
+parser.add_argument('--with-auto-mask', type=int, default=0, help='with the the mask for stationary points')
+parser.add_argument('--with-pretrain', type=int, default=1, help='with or without imagenet pretrain for resnet')
+parser.add_argument('--dataset', type=str, choices=['kitti', 'nyu'], default='kitti', help='the dataset to train')
+parser.add_argument('--pretrained-disp', dest='pretrained_disp', default=None, metavar='PATH', help='path to pre-trained dispnet model')
+parser.add_argument('--pretrained-pose', dest='pretrained_pose', default=None, metavar='PATH', help='path to pre-trained Pose net model')
+parser.add_argument('--name', dest='name', type=str, required=True, help='name of the experiment, checkpoints are stored in checpoints/name')
+parser.add_argument('--padding-mode', type=str, choices=['zeros', 'border'], default='zeros',
+                    help='padding mode for image warping : this is important for photometric differenciation when going outside target image.'
+                         ' zeros will null gradients outside target image.'
+                         ' border will only null gradients of the coordinate outside (x or y)')
+parser.add_argument('--with-gt', action='store_true', help='use ground truth for validation. \
+                    You need to store it in npy 2D arrays see data/kitti_raw_loader.py for an example')
+# extensions (not in the reference)
+parser.add_argument('--exact-mask-normalisation', action='store_true',
+                    help='data parallel: all-reduce the mask sums so the loss equals the single-process loss on the global batch')
+
+best_error = -1
+n_iter = 0
+device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+
+class _ScalarLog(object):
+    """Stand-in for tensorboardX.SummaryWriter (absent here): keeps the call sites, drops the data."""
+
+    def add_scalar(self, *a, **k):
+        pass
+
+    def add_image(self, *a, **k):
+        pass
+
+
+def build_datasets(args):
+    normalize = custom_transforms.Normalize(mean=[0.45, 0.45, 0.45], std=[0.225, 0.225, 0.225])
+    train_transform = custom_transforms.Compose([custom_transforms.RandomHorizontalFlip(), custom_transforms.RandomScaleCrop(),
+                                                 custom_transforms.ArrayToTensor(), normalize])
+    valid_transform = custom_transforms.Compose([custom_transforms.ArrayToTensor(), normalize])
+    if args.data.startswith('synthetic:'):
+        from datasets.synthetic import InMemorySequences
+        _, n, hw = args.data.split(':')
+        h, w = (int(v) for v in hw.lower().split('x'))
+        return (InMemorySequences(int(n), h, w, args.sequence_length, seed=args.seed),
+                InMemorySequences(max(int(n) // 4, args.batch_size), h, w, args.sequence_length, seed=args.seed + 1))
+    from datasets.sequence_folders import SequenceFolder
+    if args.folder_type == 'sequence':
+        train_set = SequenceFolder(args.data, transform=train_transform, seed=args.seed, train=True,
+                                   sequence_length=args.sequence_length, dataset=args.dataset)
+    else:
+        from datasets.pair_folders import PairFolder
+        train_set = PairFolder(args.data, seed=args.seed, train=True, transform=train_transform)
+    if args.with_gt:
+        from datasets.validation_folders import ValidationSet
+        val_set = ValidationSet(args.data, transform=valid_transform, dataset=args.dataset)
+    else:
+        val_set = SequenceFolder(args.data, transform=valid_transform, seed=args.seed, train=False,
+                                 sequence_length=args.sequence_length, dataset=args.dataset)
+    return train_set, val_set
+
+
+def main():
+    global best_error, n_iter, device
+    args = parser.parse_args()
+    rank, local_rank, world = hip_dist.init_process_group_from_env()
+    is_main = rank == 0
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        raise SystemExit("train.py needs a HIP device: the loss path has no CPU fallback")
+
+    timestamp = datetime.datetime.now().strftime("%m-%d-%H:%M")
+    args.save_path = os.path.join('checkpoints', args.name, timestamp)
+    if is_main:
+        print('=> will save everything to {}'.format(args.save_path))
+        os.makedirs(args.save_path, exist_ok=True)
+
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    torch.backends.cudnn.benchmark = True
+
+    training_writer = _ScalarLog()
+    output_writers = [_ScalarLog() for _ in range(3)] if args.log_output else []
+
+    if is_main:
+        print("=> fetching scenes in '{}'".format(args.data))
+    train_set, val_set = build_datasets(args)
+    if is_main:
+        print('{} samples found in {} train scenes'.format(len(train_set), len(train_set.scenes)))
+        print('{} samples found in {} valid scenes'.format(len(val_set), len(val_set.scenes)))
+    train_sampler = torch.utils.data.distributed.DistributedSampler(train_set, world, rank, shuffle=True, seed=args.seed,
+                                                                    drop_last=True) if world > 1 else None
+    train_loader = torch.utils.data.DataLoader(train_set, batch_size=args.batch_size, shuffle=train_sampler is None,
+                                               sampler=train_sampler, num_workers=args.workers, pin_memory=True,
+                                               drop_last=world > 1)
+    val_loader = torch.utils.data.DataLoader(val_set, batch_size=args.batch_size, shuffle=False,
+                                             num_workers=args.workers, pin_memory=True)
+    if args.epoch_size == 0:
+        args.epoch_size = len(train_loader)
+
+    if is_main:
+        print("=> creating model")
+    disp_net = models.DispResNet(args.resnet_layers, args.with_pretrain).to(device)
+    pose_net = models.PoseResNet(18, args.with_pretrain).to(device)
+    if args.pretrained_disp:
+        if is_main:
+            print("=> using pre-trained weights for DispResNet")
+        disp_net.load_state_dict(torch.load(args.pretrained_disp, map_location=device)['state_dict'], strict=False)
+    if args.pretrained_pose:
+        if is_main:
+            print("=> using pre-trained weights for PoseResNet")
+        pose_net.load_state_dict(torch.load(args.pretrained_pose, map_location=device)['state_dict'], strict=False)
+
+    if world > 1:
+        # gradients: one bucketed all-reduce per step over RCCL / xGMI, overlapped with backward
+        ddp = torch.nn.parallel.DistributedDataParallel
+        disp_net = ddp(disp_net, device_ids=[local_rank], bucket_cap_mb=64, gradient_as_bucket_view=True)
+        pose_net = ddp(pose_net, device_ids=[local_rank], bucket_cap_mb=64, gradient_as_bucket_view=True)
+        if args.exact_mask_normalisation:
+            hip_dist.enable_exact_normalisation()
+    args.world = world
+    # let the loss speculate on the weights its two outputs are multiplied with (scsfm_hip/config.py)
+    hip_config.set_weight_hint(args.photo_loss_weight * (world if args.exact_mask_normalisation and world > 1 else 1),
+                               args.geometry_consistency_weight * (world if args.exact_mask_normalisation and world > 1 else 1))
+
+    if is_main:
+        print('=> setting adam solver')
+    optim_params = [{'params': [p for p in disp_net.parameters() if p.requires_grad], 'lr': args.lr},
+                    {'params': [p for p in pose_net.parameters() if p.requires_grad], 'lr': args.lr}]
+    optimizer = torch.optim.Adam(optim_params, betas=(args.momentum, args.beta), weight_decay=args.weight_decay)
+
+    if is_main:
+        with open(os.path.join(args.save_path, args.log_summary), 'w') as csvfile:
+            csv.writer(csvfile, delimiter='\t').writerow(['train_loss', 'validation_loss'])
+        with open(os.path.join(args.save_path, args.log_full), 'w') as csvfile:
+            csv.writer(csvfile, delimiter='\t').writerow(['train_loss', 'photo_loss', 'smooth_loss', 'geometry_consistency_loss'])
+
+    logger = TermLogger(n_epochs=args.epochs, train_size=min(len(train_loader), args.epoch_size), valid_size=len(val_loader))
+    logger.epoch_bar.start()
+    for epoch in range(args.epochs):
+        logger.epoch_bar.update(epoch)
+        if train_sampler is not None:
+            train_sampler.set_epoch(epoch)
+        logger.reset_train_bar()
+        train_loss = train(args, train_loader, disp_net, pose_net, optimizer, args.epoch_size, logger, training_writer, is_main)
+        if is_main:
+            logger.train_writer.write(' * Avg Loss : {:.3f}'.format(train_loss))
+
+        # validation and checkpoints on rank 0 (the nets are identical on every rank after the step)
+        if is_main:
+            logger.reset_valid_bar()
+            d_net = disp_net.module if world > 1 else disp_net
+            p_net = pose_net.module if world > 1 else pose_net
+            if args.with_gt:
+                errors, error_names = validate_with_gt(args, val_loader, d_net, epoch, logger, output_writers)
+            else:
+                errors, error_names = validate_without_gt(args, val_loader, d_net, p_net, epoch, logger, output_writers)
+            logger.valid_writer.write(' * Avg {}'.format(', '.join('{} : {:.3f}'.format(n, e) for n, e in zip(error_names, errors))))
+            for error, name in zip(errors, error_names):
+                training_writer.add_scalar(name, error, epoch)
+            decisive_error = errors[1]
+            if best_error < 0:
+                best_error = decisive_error
+            is_best = decisive_error < best_error
+            best_error = min(best_error, decisive_error)
+            save_checkpoint(args.save_path, {'epoch': epoch + 1, 'state_dict': d_net.state_dict()},
+                            {'epoch': epoch + 1, 'state_dict': p_net.state_dict()}, is_best)
+            with open(os.path.join(args.save_path, args.log_summary), 'a') as csvfile:
+                csv.writer(csvfile, delimiter='\t').writerow([train_loss, decisive_error])
+        if world > 1:
+            torch.distributed.barrier()
+    logger.epoch_bar.finish()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def train_step(args, disp_net, pose_net, optimizer, tgt_img, ref_imgs, intrinsics):
+    """One optimisation step on device tensors (train.py:258-282).  Returns the four losses (tensors)."""
+    w1, w2, w3 = args.photo_loss_weight, args.smooth_loss_weight, args.geometry_consistency_weight
+    tgt_depth, ref_depths = compute_depth(disp_net, tgt_img, ref_imgs)
+    poses, poses_inv = compute_pose_with_inv(pose_net, tgt_img, ref_imgs)
+    loss_1, loss_3 = compute_photo_and_geometry_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, poses, poses_inv,
+                                                     args.num_scales, args.with_ssim, args.with_mask, args.with_auto_mask,
+                                                     args.padding_mode)
+    loss_2 = compute_smooth_loss(tgt_depth, tgt_img, ref_depths, ref_imgs)
+    loss = w1 * loss_1 + w2 * loss_2 + w3 * loss_3
+    optimizer.zero_grad(set_to_none=True)
+    # exact mode: every rank holds the GLOBAL loss and DDP averages gradients -> scale by the world size
+    scale = getattr(args, 'world', 1) if getattr(args, 'exact_mask_normalisation', False) else 1
+    (loss * scale if scale != 1 else loss).backward()
+    optimizer.step()
+    return loss, loss_1, loss_2, loss_3
+
+
+def train(args, train_loader, disp_net, pose_net, optimizer, epoch_size, logger, train_writer, is_main=True):
+    global n_iter, device
+    batch_time = AverageMeter()
+    data_time = AverageMeter()
+    losses = AverageMeter(precision=4)
+    disp_net.train()
+    pose_net.train()
+    end = time.time()
+    logger.train_bar.update(0)
+    for i, (tgt_img, ref_imgs, intrinsics, intrinsics_inv) in enumerate(train_loader):
+        log_losses = i > 0 and n_iter % args.print_freq == 0
+        data_time.update(time.time() - end)
+        tgt_img = tgt_img.to(device, non_blocking=True)
+        ref_imgs = [img.to(device, non_blocking=True) for img in ref_imgs]
+        intrinsics = intrinsics.to(device, non_blocking=True).float()
+
+        loss, loss_1, loss_2, loss_3 = train_step(args, disp_net, pose_net, optimizer, tgt_img, ref_imgs, intrinsics)
+
+        # one host read-back per step instead of the reference's five .item() calls (train.py:277,290)
+        vals = torch.stack([loss.detach(), loss_1.detach(), loss_2.detach(), loss_3.detach()]).tolist()
+        if log_losses:
+            train_writer.add_scalar('photometric_error', vals[1], n_iter)
+            train_writer.add_scalar('disparity_smoothness_loss', vals[2], n_iter)
+            train_writer.add_scalar('geometry_consistency_loss', vals[3], n_iter)
+            train_writer.add_scalar('total_loss', vals[0], n_iter)
+        losses.update(vals[0], args.batch_size)
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if is_main:
+            with open(os.path.join(args.save_path, args.log_full), 'a') as csvfile:
+                csv.writer(csvfile, delimiter='\t').writerow(vals)
+            logger.train_bar.update(i + 1)
+            if i % args.print_freq == 0:
+                logger.train_writer.write('Train: Time {} Data {} Loss {}'.format(batch_time, data_time, losses))
+        if i >= epoch_size - 1:
+            break
+        n_iter += 1
+    return losses.avg[0]
+
+
+@torch.no_grad()
+def validate_without_gt(args, val_loader, disp_net, pose_net, epoch, logger, output_writers=[]):
+    """Photometric / smoothness / geometry losses on the validation split, auto-mask off
+    (train.py:302-362)."""
+    global device
+    batch_time = AverageMeter()
+    losses = AverageMeter(i=4, precision=4)
+    disp_net.eval()
+    pose_net.eval()
+    end = time.time()
+    logger.valid_bar.update(0)
+    for i, (tgt_img, ref_imgs, intrinsics, intrinsics_inv) in enumerate(val_loader):
+        tgt_img = tgt_img.to(device)
+        ref_imgs = [img.to(device) for img in ref_imgs]
+        intrinsics = intrinsics.to(device).float()
+        tgt_depth = [1 / disp_net(tgt_img)]
+        ref_depths = [[1 / disp_net(ref_img)] for ref_img in ref_imgs]
+        poses, poses_inv = compute_pose_with_inv(pose_net, tgt_img, ref_imgs)
+        loss_1, loss_3 = compute_photo_and_geometry_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, poses, poses_inv,
+                                                         args.num_scales, args.with_ssim, args.with_mask, False, args.padding_mode)
+        loss_2 = compute_smooth_loss(tgt_depth, tgt_img, ref_depths, ref_imgs)
+        losses.update([float(loss_1), float(loss_1), float(loss_2), float(loss_3)])
+        batch_time.update(time.time() - end)
+        end = time.time()
+        logger.valid_bar.update(i + 1)
+        if i % args.print_freq == 0:
+            logger.valid_writer.write('valid: Time {} Loss {}'.format(batch_time, losses))
+    logger.valid_bar.update(len(val_loader))
+    return losses.avg, ['Total loss', 'Photo loss', 'Smooth loss', 'Consistency loss']
+
+
+@torch.no_grad()
+def validate_with_gt(args, val_loader, disp_net, epoch, logger, output_writers=[]):
+    """Depth metrics against ground truth; errors[1] (abs_rel) selects the best model
+    (train.py:365-423)."""
+    global device
+    batch_time = AverageMeter()
+    error_names = ['abs_diff', 'abs_rel', 'sq_rel', 'a1', 'a2', 'a3']
+    errors = AverageMeter(i=len(error_names))
+    disp_net.eval()
+    end = time.time()
+    logger.valid_bar.update(0)
+    for i, (tgt_img, depth) in enumerate(val_loader):
+        tgt_img = tgt_img.to(device)
+        depth = depth.to(device)
+        if depth.nelement() == 0:
+            continue
+        output_disp = disp_net(tgt_img)
+        output_depth = 1 / output_disp[:, 0]
+        if depth.nelement() != output_depth.nelement():
+            b, h, w = depth.size()
+            output_depth = torch.nn.functional.interpolate(output_depth.unsqueeze(1), [h, w]).squeeze(1)
+        errors.update(compute_errors(depth, output_depth, args.dataset))
+        batch_time.update(time.time() - end)
+        end = time.time()
+        logger.valid_bar.update(i + 1)
+        if i % args.print_freq == 0:
+            logger.valid_writer.write('valid: Time {} Abs Error {:.4f} ({:.4f})'.format(batch_time, errors.val[0], errors.avg[0]))
+    logger.valid_bar.update(len(val_loader))
+    return errors.avg, error_names
+
+
+def compute_depth(disp_net, tgt_img, ref_imgs):
+    tgt_depth = [1 / disp for disp in disp_net(tgt_img)]
+    ref_depths = [[1 / disp for disp in disp_net(ref_img)] for ref_img in ref_imgs]
+    return tgt_depth, ref_depths
+
+
+def compute_pose_with_inv(pose_net, tgt_img, ref_imgs):
+    poses, poses_inv = [], []
+    for ref_img in ref_imgs:
+        poses.append(pose_net(tgt_img, ref_img))
+        poses_inv.append(pose_net(ref_img, tgt_img))
+    return poses, poses_inv
+
+
+if __name__ == '__main__':
+    main()
