@@ -17,14 +17,16 @@ def test_train_py_runs_and_writes_reference_checkpoints(tmp_path):
            "-b", "2", "-s", "0.1", "-c", "0.5", "--epoch-size", "3", "--epochs", "1", "--sequence-length", "3",
            "--with-ssim", "1", "--with-mask", "1", "--with-auto-mask", "1", "--with-pretrain", "0", "-j", "0",
            "--name", "smoke"]
-    env = dict(os.environ, PYTHONPATH=PKG)
+    env = dict(os.environ, PYTHONPATH=PKG, MIOPEN_FIND_MODE="FAST")  # train.py turns cudnn.benchmark on (train.py:83)
     out = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     run_dir = os.path.join(tmp_path, "checkpoints", "smoke")
     stamp = os.listdir(run_dir)[0]
     files = set(os.listdir(os.path.join(run_dir, stamp)))
-    assert {"dispnet_checkpoint.pth.tar", "exp_pose_checkpoint.pth.tar", "dispnet_model_best.pth.tar",
-            "exp_pose_model_best.pth.tar", "progress_log_summary.csv", "progress_log_full.csv"} <= files
+    # after the first epoch the reference has not yet written *_model_best: is_best compares the decisive
+    # error with itself (train.py:212-216)
+    assert {"dispnet_checkpoint.pth.tar", "exp_pose_checkpoint.pth.tar", "progress_log_summary.csv",
+            "progress_log_full.csv"} <= files and "dispnet_model_best.pth.tar" not in files
     rows = open(os.path.join(run_dir, stamp, "progress_log_full.csv")).read().strip().split("\n")
     assert rows[0].split("\t") == ["train_loss", "photo_loss", "smooth_loss", "geometry_consistency_loss"]
     vals = [[float(v) for v in r.split("\t")] for r in rows[1:]]
