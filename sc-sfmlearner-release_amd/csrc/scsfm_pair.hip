@@ -224,8 +224,10 @@ __global__ void pair_refinalize_kernel(double* __restrict__ sums, T* __restrict_
 // backward -- forward statistics at every pixel of the 64 x TH domain, then the transpose of
 // (reflect-pad + box) as a separable 3x3 gather -- and writes four planes for the 62 x (TH-2)
 // interior: gbuf[c] = dL/dI_w,c (c = 0..2), gbuf[3] = dL/d diff_depth.  Pass B consumes them.
-// Splitting here keeps both halves at a register budget that sustains >= 4 waves per SIMD; fused,
-// the kernel needed 256 VGPRs (1 wave per SIMD) and could not hide its gather latency.
+// Splitting here keeps both halves at a register budget that sustains 3-4 waves per SIMD; fused, the
+// kernel needed 256 VGPRs (1 wave per SIMD) and could not hide its gather latency.  (This half is
+// bounded to 3 waves per SIMD: at 4 it spills 52 B per lane, and that scratch traffic doubled its
+// WRITE_SIZE and cost 9 % -- profiles/r01c.)
 // ==========================================================================================
 //
 // kSpec = true is the SPECULATIVE FORWARD: the same kernel run as the forward pass, with unit photo
@@ -245,7 +247,7 @@ __device__ __forceinline__ bool spec_valid(const double* __restrict__ sums, cons
 }
 
 template <typename T, bool kSsim, bool kSpec>
-__global__ __launch_bounds__(kThreads, 4) void pair_bwd_photo_kernel(
+__global__ __launch_bounds__(kThreads, 3) void pair_bwd_photo_kernel(
     PairBatch<T> pb, int B, int H, int W, unsigned flags, const T* __restrict__ g_photo,
     const T* __restrict__ g_geom, T r_hint) {
   const int pair = blockIdx.z / B, b = blockIdx.z - pair * B;

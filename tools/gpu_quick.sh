@@ -1,4 +1,5 @@
 set +e
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_trainer.py -m gpu -q -x 2>&1 | grep -v "^$" | tail -40 | cut -c1-400
+python bench.py --steps 50 --warmup 10 --cpu-seconds 0 --e2e-steps 0 2>/dev/null | tee gpurun_out/bench_quick.json | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['kernel_us'])"
