@@ -169,6 +169,9 @@ struct Sample {
   T w[4];           // bilinear weights of the taps (0 nw, 1 ne, 2 sw, 3 se); 0 for taps outside the image
   unsigned off[4];  // element offset of each tap inside a plane, clamped into the image so that the
                     // four loads need no predication (their weight is 0 when they were clamped)
+  unsigned offr[2]; // element offset of the (west, east) tap PAIR of the north / south row: the west column is
+                    // clamped to [0, W-2] so that one 8-byte load fetches both taps of a row
+  int xsel;         // x0 - clamped west column: -1 / 0 / +1 tells which half of the pair is which tap
   unsigned inb;     // bit k: tap k lies inside the image
   int x0, y0;       // north-west tap (unclamped)
   bool valid;       // max(|xn|, |yn|) <= 1   (inverse_warp.py:264)
@@ -228,13 +231,24 @@ __device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int
   const int r0 = t_clampi(y0, 0, H - 1) * W, r1 = t_clampi(y1, 0, H - 1) * W;
   s.off[0] = unsigned(r0 + xc0); s.off[1] = unsigned(r0 + xc1);
   s.off[2] = unsigned(r1 + xc0); s.off[3] = unsigned(r1 + xc1);
+  const int xa = t_clampi(x0, 0, W - 2);
+  s.offr[0] = unsigned(r0 + xa); s.offr[1] = unsigned(r1 + xa);
+  s.xsel = x0 - xa;
   return s;
 }
 
-// The four taps of one plane.  Unpredicated: clamped addresses, zero weights for clamped taps.
+// The four taps of one plane.  Unpredicated, two 8-byte loads (global_load_dwordx2 needs only dword
+// alignment): each row's pair starts at a west column clamped to [0, W-2]; when the sampling position
+// straddles the left / right image border (xsel = -1 / +1) the in-image tap sits in the other half of
+// the pair and the out-of-image tap has weight 0 whatever it reads.
+template <typename T>
+struct TapPair { T a, b; };
 template <typename T>
 __device__ __forceinline__ void load_taps(const T* __restrict__ plane, const Sample<T>& s, T* v) {
-  v[0] = plane[s.off[0]]; v[1] = plane[s.off[1]]; v[2] = plane[s.off[2]]; v[3] = plane[s.off[3]];
+  const TapPair<T> n = *reinterpret_cast<const TapPair<T>*>(plane + s.offr[0]);
+  const TapPair<T> so = *reinterpret_cast<const TapPair<T>*>(plane + s.offr[1]);
+  v[0] = s.xsel == 1 ? n.b : n.a;  v[1] = s.xsel == -1 ? n.a : n.b;
+  v[2] = s.xsel == 1 ? so.b : so.a; v[3] = s.xsel == -1 ? so.a : so.b;
 }
 
 template <typename T>

@@ -139,7 +139,9 @@ def main():
 
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
-    torch.backends.cudnn.benchmark = True
+    # the reference turns the conv auto-tuner on (train.py:83); on MIOpen the first step then pays a
+    # per-layer search, which short smoke runs can switch off
+    torch.backends.cudnn.benchmark = os.environ.get("SCSFM_CUDNN_BENCHMARK", "1") != "0"
 
     training_writer = _ScalarLog()
     output_writers = [_ScalarLog() for _ in range(3)] if args.log_output else []
