@@ -325,10 +325,11 @@ __device__ __forceinline__ void scatter_taps_window(T (*win)[kWinW], int wx0, in
   if (g == T(0)) return;
   const int lx = s.x0 - wx0, ly = s.y0 - wy0;
   if (lx >= 0 && lx < kWinW - 1 && ly >= 0 && ly < kWinH - 1) {
-    if (s.inb & 1u) atomicAdd(&win[ly][lx], g * s.w[0]);
-    if (s.inb & 2u) atomicAdd(&win[ly][lx + 1], g * s.w[1]);
-    if (s.inb & 4u) atomicAdd(&win[ly + 1][lx], g * s.w[2]);
-    if (s.inb & 8u) atomicAdd(&win[ly + 1][lx + 1], g * s.w[3]);
+    // unpredicated: an out-of-image tap has weight 0, and adding 0 leaves its cell at the 0 the flush skips
+    atomicAdd(&win[ly][lx], g * s.w[0]);
+    atomicAdd(&win[ly][lx + 1], g * s.w[1]);
+    atomicAdd(&win[ly + 1][lx], g * s.w[2]);
+    atomicAdd(&win[ly + 1][lx + 1], g * s.w[3]);
   } else {
     scatter_taps(gplane, s, g);
   }

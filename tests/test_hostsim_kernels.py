@@ -309,3 +309,42 @@ def test_speculative_forward_fp64(lib, hint, upstream):
     for i in range(2):
         assert _rel(g_rd[i][0], z(rd[i][0])) < 1e-10
         assert _rel(g_p[i], z(pp[i])) < 1e-10 and _rel(g_pi[i], z(pi[i])) < 1e-10
+
+
+@pytest.mark.parametrize("hint", [(1.0, 0.5), None])
+def test_more_pair_directions_than_one_launch_holds(lib, hint):
+    """3 refs x 2 scales x 2 directions = 12 pair-directions > kMaxPairs (8): the library splits them
+    over two launches per stage; every gradient buffer still sees every contribution."""
+    d = synth.make_batch(2, 64, 96, n_ref=3, seed=29, depth="smooth", num_scales=2)
+    c = lambda x: x.double().contiguous()
+    H, W = 64, 96
+    up = lambda t: F.interpolate(t, (H, W), mode="nearest") if t.shape[-1] != W else t
+    ti, K = c(d["tgt_img"]), c(d["intrinsics"])
+    ris = [c(r) for r in d["ref_imgs"]]
+    tds = [c(up(t)) for t in d["tgt_depth"]]
+    rds = [[c(up(t)) for t in r] for r in d["ref_depths"]]
+    ps, pis = [c(p) for p in d["poses"]], [c(p) for p in d["poses_inv"]]
+    fl = capi.make_flags(1, 1, 0, "zeros")
+    td, rd = [leaf(t) for t in tds], [[leaf(t) for t in r] for r in rds]
+    pp, pi = [leaf(p) for p in ps], [leaf(p) for p in pis]
+    # oracle on the already up-sampled maps: treat each scale as an extra full-resolution pair
+    photo_o = geom_o = 0
+    for i in range(3):
+        for s in range(2):
+            a = O.pairwise_loss(ti, ris[i], td[s], rd[i][s], pp[i], K, 1, 1, 0, "zeros")
+            b = O.pairwise_loss(ris[i], ti, rd[i][s], td[s], pi[i], K, 1, 1, 0, "zeros")
+            photo_o = photo_o + a[0] + b[0]
+            geom_o = geom_o + a[1] + b[1]
+    (1.0 * photo_o + 0.5 * geom_o).backward()
+    photo, geom, outs, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=hint)
+    assert outs.shape[0] == 12
+    assert abs(float(photo) - float(photo_o)) < 1e-11 and abs(float(geom) - float(geom_o)) < 1e-11
+    g_td, g_rd, g_p, g_pi = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws,
+                                                    torch.tensor([1.0], dtype=torch.float64),
+                                                    torch.tensor([0.5], dtype=torch.float64))
+    for s in range(2):
+        assert _rel(g_td[s], td[s].grad) < 1e-10
+        for i in range(3):
+            assert _rel(g_rd[i][s], rd[i][s].grad) < 1e-10
+    for i in range(3):
+        assert _rel(g_p[i], pp[i].grad) < 1e-10 and _rel(g_pi[i], pi[i].grad) < 1e-10
