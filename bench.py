@@ -72,6 +72,21 @@ def hot_path_step(LF, x, flags):
     return loss, photo, smooth, geom
 
 
+def pmc_traffic(args, n_pairs):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_latest.json:
+    FETCH_SIZE + WRITE_SIZE in KiB per dispatch, collected in separate `rocprofv3 --pmc` runs of this very
+    command -- tools/gpu_round.sh).  Only quoted for the workload the counters were collected on."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path) or (args.batch, args.height, args.width, args.n_ref, args.depth) != (12, 256, 832, 2, "smooth"):
+        return None
+    try:
+        d = json.load(open(path))
+        k = d[f"scsfm::pair_bwd_photo_kernel<float, true, true>|gz{n_pairs * args.batch}"]
+        return int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
+    except (KeyError, ValueError):
+        return None
+
+
 def _event_time(fn, iters):
     for _ in range(3):
         fn()
@@ -284,7 +299,7 @@ def main():
     achieved = spec_bytes / kt["pairs_fwd_spec"] / 1e9
     roofline = {"bound": "hbm", "kernel": f"pair_bwd_photo_kernel<float,true,true> ({n_pairs} pair-directions per launch)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, n_pairs),
                 "algorithmic_bytes_per_launch": spec_bytes, "avg_launch_us": round(kt["pairs_fwd_spec"] * 1e6, 2)}
     # SURVEY.md 8d figure: one pair-direction forward + backward = 48 B/px
     pair_t = (kt["pairs_fwd_spec"] + kt["pairs_bwd_after_spec"]) / n_pairs
