@@ -243,6 +243,20 @@ int scsfm_smooth_multi_bwd_f64(int n, const void* const* depths, const void* con
                                int W, void* ws, const double* g_loss, void* const* g_depths,
                                void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The training input transform on the device (train.py:95-100; custom_transforms.py:33-84):
+ * RandomHorizontalFlip -> RandomScaleCrop (Pillow bicubic, byte-exact) -> ArrayToTensor -> Normalize.
+ * frames: uint8 [n_frames, H, W, 3] (decoded images, HWC); consecutive groups of frames_per_sample frames
+ * share one record of params [n_samples][8] = {flip, ...} and one row of the coefficient tables
+ * htab [n_samples][W][8], vtab [n_samples][H][8] = {first source index, tap count, 5 fixed-point taps, -}
+ * (prepared on the host as Pillow's precompute_coeffs + normalize_coeffs_8bpc do, for the cropped window);
+ * lut [256] = the float a byte maps to; out: fp32 [frames_per_sample, n_samples, 3, H, W] (store): frame-major,
+ * so that out[t] is the contiguous batch of the t-th frame of every sample.
+ * --------------------------------------------------------------------------------------------- */
+int scsfm_augment_u8_f32(int n_frames, int frames_per_sample, int H, int W, const unsigned char* frames,
+                         const int* params, const int* htab, const int* vtab, const float* lut, float* out,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,3 +68,11 @@ class RandomScaleCrop(object):
         out_k[0, 2] -= ox
         out_k[1, 2] -= oy
         return [im[oy:oy + in_h, ox:ox + in_w] for im in scaled], out_k
+
+
+class ArrayToUint8(object):
+    """Extension for the device-side transform (scsfm_hip/augment.py): keep the decoded frames as
+    HxWx3 uint8 tensors; flip / zoom-crop / normalisation then run on the GPU."""
+
+    def __call__(self, images, intrinsics):
+        return [torch.from_numpy(np.ascontiguousarray(im).astype(np.uint8)) for im in images], intrinsics

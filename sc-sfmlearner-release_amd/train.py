@@ -75,6 +75,9 @@ parser.add_argument('--padding-mode', type=str, choices=['zeros', 'border'], def
 parser.add_argument('--with-gt', action='store_true', help='use ground truth for validation. \
                     You need to store it in npy 2D arrays see data/kitti_raw_loader.py for an example')
 # extensions (not in the reference)
+parser.add_argument('--gpu-augment', action='store_true',
+                    help='run flip / zoom-crop / normalisation on the GPU (byte-exact with the PIL transform chain) '
+                         'instead of in the data-loader workers')
 parser.add_argument('--exact-mask-normalisation', action='store_true',
                     help='data parallel: all-reduce the mask sums so the loss equals the single-process loss on the global batch')
 
@@ -98,6 +101,8 @@ def build_datasets(args):
     train_transform = custom_transforms.Compose([custom_transforms.RandomHorizontalFlip(), custom_transforms.RandomScaleCrop(),
                                                  custom_transforms.ArrayToTensor(), normalize])
     valid_transform = custom_transforms.Compose([custom_transforms.ArrayToTensor(), normalize])
+    if args.gpu_augment:  # workers only decode; the transform chain runs in scsfm_hip.augment
+        train_transform = custom_transforms.Compose([custom_transforms.ArrayToUint8()])
     if args.data.startswith('synthetic:'):
         from datasets.synthetic import InMemorySequences
         _, n, hw = args.data.split(':')
@@ -270,6 +275,13 @@ def train(args, train_loader, disp_net, pose_net, optimizer, epoch_size, logger,
         data_time.update(time.time() - end)
         tgt_img = tgt_img.to(device, non_blocking=True)
         ref_imgs = [img.to(device, non_blocking=True) for img in ref_imgs]
+        if args.gpu_augment and tgt_img.dtype == torch.uint8:
+            from scsfm_hip import augment as hip_augment
+            frames = torch.stack([tgt_img] + ref_imgs, dim=1).contiguous()  # [B, T, H, W, 3] uint8
+            recs = hip_augment.draw_params(frames.shape[0], frames.shape[2], frames.shape[3])
+            out = hip_augment.augment(frames, recs)                          # [T, B, 3, H, W] fp32
+            tgt_img, ref_imgs = out[0], [out[i] for i in range(1, out.shape[0])]
+            intrinsics = torch.from_numpy(hip_augment.update_intrinsics(intrinsics.numpy(), recs, frames.shape[3]))
         intrinsics = intrinsics.to(device, non_blocking=True).float()
 
         loss, loss_1, loss_2, loss_3 = train_step(args, disp_net, pose_net, optimizer, tgt_img, ref_imgs, intrinsics)

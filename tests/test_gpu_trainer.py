@@ -36,3 +36,23 @@ def test_train_py_runs_and_writes_reference_checkpoints(tmp_path):
     blob = torch.load(os.path.join(run_dir, stamp, "dispnet_checkpoint.pth.tar"), map_location="cpu")
     assert blob["epoch"] == 1
     models.DispResNet(18, False).load_state_dict(blob["state_dict"], strict=True)
+
+
+def test_train_py_with_disk_dataset_and_gpu_augment(tmp_path):
+    """The data path end to end: an on-disk tree in the reference's SequenceFolder layout, JPEG decoding
+    in the loader, flip / zoom-crop / normalise on the GPU (scsfm_hip.augment), ground-truth validation
+    (compute_errors)."""
+    sys.path.insert(0, PKG)
+    from datasets.synthetic import write_sequence_tree
+    root = write_sequence_tree(str(tmp_path / "kitti_256"), n_scenes=2, frames_per_scene=6, height=128, width=416)
+    cmd = [sys.executable, os.path.join(PKG, "train.py"), root, "--resnet-layers", "18", "-b", "2", "--epoch-size", "2",
+           "--epochs", "1", "--with-auto-mask", "1", "--with-pretrain", "0", "-j", "1", "--with-gt", "--gpu-augment",
+           "--name", "disk"]
+    env = dict(os.environ, PYTHONPATH=PKG, SCSFM_CUDNN_BENCHMARK="0")
+    out = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "abs_rel" in out.stdout  # validate_with_gt ran
+    run_dir = os.path.join(tmp_path, "checkpoints", "disk")
+    stamp = os.listdir(run_dir)[0]
+    summary = open(os.path.join(run_dir, stamp, "progress_log_summary.csv")).read().strip().split("\n")
+    assert summary[0].split("\t") == ["train_loss", "validation_loss"] and len(summary) == 2
