@@ -12,7 +12,13 @@ _hint = (1.0, 0.5)
 def set_weight_hint(w_photo, w_geom):
     """Tell the loss which upstream-gradient ratio to speculate on; ``None, None`` disables it."""
     global _hint
-    _hint = None if w_photo is None else (float(w_photo), float(w_geom))
+    if w_photo is None:
+        _hint = None
+        return
+    # the upstream gradients arrive as fp32 tensors: compare against the fp32 roundings of the weights
+    # (the device-side check is an exact equality of products)
+    import numpy as np
+    _hint = (float(np.float32(w_photo)), float(np.float32(w_geom)))
 
 
 def weight_hint():

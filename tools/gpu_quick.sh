@@ -1,3 +1,5 @@
 set +e
 export TMPDIR=/tmp
-MIOPEN_FIND_MODE=FAST timeout 900 python tools/e2e_probe.py 2>&1 | grep -v Warning | tail -4
+mkdir -p gpurun_out
+python bench.py --steps 50 --warmup 10 --cpu-seconds 0 --e2e-steps 0 2>/dev/null | tee gpurun_out/bench_quick.json | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['kernel_us'])"
