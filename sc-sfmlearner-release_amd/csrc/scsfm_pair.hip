@@ -430,7 +430,6 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
   constexpr int ROWS = 4;  // pixels per thread: a block covers a 64 x 16 tile
   __shared__ double red[12 * (kThreads / kWave)];
   __shared__ T win[kWinH][kWinW];  // staging window of the scatter into dL/d ref_depth
-  __shared__ int win_org[2];
   if (T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0)) return;  // as in pass A
   // planes left by a speculative forward lack the common factor a = g_photo / (3 S_m)
   const T gscale = spec_valid(sums, g_photo, g_geom) ? T(sums[5]) * g_photo[0] : T(1);
@@ -445,27 +444,40 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
   g_tgt_depth += (size_t)b * plane;
   g_ref_depth += (size_t)b * plane;
   gbuf += (size_t)b * plane;
-  // window origin: centred on where the tile's centre pixel lands in the reference view
   for (int i = threadIdx.x; i < kWinW * kWinH; i += kThreads) (&win[0][0])[i] = T(0);
-  if (threadIdx.x == 2 * kWave + kWave / 2) {
-    const int cx = px < W ? px : W - 1, cy = py0 < H ? py0 : H - 1;
-    const Sample<T> sc = project_pixel(bc, cx, cy, tgt_depth[unsigned(cy) * unsigned(W) + unsigned(cx)], H, W, flags);
-    win_org[0] = sc.x0 - kWinW / 2;
-    win_org[1] = sc.y0 - kWinH / 2;
-  }
   __syncthreads();
-  const int wx0 = win_org[0], wy0 = win_org[1];
+  // window origin: centred on where the tile's centre pixel lands in the reference view.  Every thread
+  // evaluates it (one broadcast load + one projection): handing it over from a single thread would put
+  // that thread's dependent load in front of a barrier for the whole block.
+  int wx0, wy0;
+  {
+    const int ax = t_clampi(blockIdx.x * kWave + kWave / 2, 0, W - 1);
+    const int ay = t_clampi(blockIdx.y * (kThreads / kWave) * ROWS + 2 * ROWS, 0, H - 1);
+    const Sample<T> sc = project_pixel(bc, ax, ay, tgt_depth[unsigned(ay) * unsigned(W) + unsigned(ax)], H, W, flags);
+    wx0 = sc.x0 - kWinW / 2;
+    wy0 = sc.y0 - kWinH / 2;
+  }
   T acc[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) acc[i] = T(0);
+  // all streaming loads of the strip first (5 per pixel), so that they are in flight together before the
+  // first dependent gather
+  T in_d[ROWS], in_g[ROWS][4];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int py = py0 + r;
+    const unsigned p = unsigned(py < H ? py : H - 1) * unsigned(W) + unsigned(px < W ? px : W - 1);
+    in_d[r] = tgt_depth[p];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) in_g[r][c] = gbuf[c * gplane + p];
+  }
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     const int py = py0 + r;
     if (px >= W || py >= H) continue;
     const unsigned p = unsigned(py) * unsigned(W) + unsigned(px);
-    const T d = tgt_depth[p];
-    const T gI0 = gscale * gbuf[p], gI1 = gscale * gbuf[gplane + p], gI2 = gscale * gbuf[2 * gplane + p],
-            g_dd = gscale * gbuf[3 * gplane + p];
+    const T d = in_d[r];
+    const T gI0 = gscale * in_g[r][0], gI1 = gscale * in_g[r][1], gI2 = gscale * in_g[r][2], g_dd = gscale * in_g[r][3];
     const Sample<T> s = project_pixel(bc, px, py, d, H, W, flags);
     const SampleGrad<T> sg = sample_grad(s);
     T t[4];
