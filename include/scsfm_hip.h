@@ -44,6 +44,9 @@ extern "C" {
 #define SCSFM_DEBUG_X3 4096u  /* no 12-value block reduction / gP atomics */
 #define SCSFM_DEBUG_X4 8192u  /* no colour-tap gathers */
 
+#define SCSFM_DEBUG_KERNEL_ONLY 16384u /* scsfm_pairs_fwd only, for timing: launch the main kernel alone (the
+                                          constants of an earlier identical call are still in `ws`) */
+
 #define SCSFM_ROT_EULER 0 /* inverse_warp.py:77-112  */
 #define SCSFM_ROT_QUAT 1  /* inverse_warp.py:115-136 */
 

@@ -251,7 +251,7 @@ def _pair_list(tgt_img, ref_imgs, tgt_depths, ref_depths, poses, poses_inv):
 
 
 def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, group=None,
-                       hint=None):
+                       hint=None, ws=None):
     """All pair-directions of loss_functions.py:56-90 in ONE call into the library.  ``tgt_depths[s]``
     and ``ref_depths[i][s]`` are full-resolution maps.  Returns (photo, geom, outs [n_pairs, 8], ws)
     where ``ws`` (one tensor, n_pairs slices) must reach photo_geometry_bwd untouched.
@@ -279,7 +279,8 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
     ws_bytes, scratch_bytes, _ = _sizes(lib, B, H, W)
     spec = hint is not None and float(hint[0]) != 0.0
     stride = ws_bytes + (scratch_bytes if spec else 0)  # per pair: workspace, then (speculative) the gbuf planes
-    ws = torch.empty(n * stride, dtype=torch.uint8, device=tgt_img.device)
+    if ws is None:
+        ws = torch.empty(n * stride, dtype=torch.uint8, device=tgt_img.device)
     outs = torch.empty(n, 8, dtype=tgt_img.dtype, device=tgt_img.device)
     descs = (PairDesc * n)()
     wp, op, esz = ws.data_ptr(), outs.data_ptr(), outs.element_size() * 8
@@ -298,6 +299,8 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         outs[:, 2:5] = sums
         for j in range(n):
             pair_refinalize(lib, (B, H, W), ws[j * stride:j * stride + ws_bytes], outs[j])
+    if flags & 16384:  # SCSFM_DEBUG_KERNEL_ONLY (bench.py): nothing was finalised
+        return None, None, outs, ws
     tot = outs[:, :2].sum(dim=0)  # plain sums over refs, scales and directions (loss_functions.py:89-90)
     return tot[0], tot[1], outs, ws
 
