@@ -106,6 +106,25 @@ __device__ __forceinline__ void block_sum(T (&v)[N], double* scratch) {
   }
 }
 
+// XCD-aware block order.  The dispatcher hands consecutive workgroups to the 8 XCDs round-robin (observed,
+// not contractual: used for speed only), so with the natural order horizontally adjacent tiles -- which
+// share ring pixels and gather from the same neighbourhood -- sit on different, mutually non-coherent L2s.
+// This bijection gives XCD k the k-th contiguous eighth of the logical (x fastest, then y, then z) order,
+// i.e. whole images per XCD.
+struct BlockId { int x, y, z; };
+__device__ __forceinline__ BlockId xcd_block_id() {
+  const int nx = gridDim.x, ny = gridDim.y, n = nx * ny * (int)gridDim.z;
+  const int p = ((int)blockIdx.z * ny + (int)blockIdx.y) * nx + (int)blockIdx.x;
+  const int xcd = p & 7, slot = p >> 3, q = n >> 3, r = n & 7;
+  const int l = xcd * q + (xcd < r ? xcd : r) + slot;
+  BlockId b;
+  b.x = l % nx;
+  const int t = l / nx;
+  b.y = t % ny;
+  b.z = t / ny;
+  return b;
+}
+
 __device__ __forceinline__ int reflect_index(int i, int n) {
   // ReflectionPad2d(1) index map (pad[-1] = x[1], pad[n] = x[n-2]); clamped so that positions
   // further out (partial tiles) stay addressable -- their values are never used.
