@@ -232,19 +232,22 @@ int scsfm_masked_mean_fwd_f64(int B, int C, int Cm, int HW, const double* diff, 
 int scsfm_masked_mean_bwd_f64(int B, int C, int Cm, int HW, const double* mask, void* ws,
                               const double* g, double* g_diff, void* stream);
 
-/* compute_smooth_loss (loss_functions.py:154-159): n frames per call.  depths / imgs / g_depths are
- * HOST arrays of n DEVICE pointers; ws = n * scsfm_smooth_ws_bytes(B,H,W) bytes; out[n] (device,
- * store) holds one loss per frame; a NULL g_depths[i] skips that frame's gradient. */
+/* compute_smooth_loss (loss_functions.py:154-159): n frames per call.  depths / imgs / g_depths / edges
+ * are HOST arrays of n DEVICE pointers; ws = n * scsfm_smooth_ws_bytes(B,H,W) bytes; out[n] (device,
+ * store) holds one loss per frame; a NULL g_depths[i] skips that frame's gradient.
+ * edges (may be NULL, as may any entry): per frame a [B,H,W] plane in which the forward leaves each
+ * pixel's summed edge terms; given the same plane, the backward is a pure stream (4 B read + 8 B
+ * read-modify-write per pixel) instead of re-evaluating the edge weights from the images. */
 int scsfm_smooth_multi_fwd_f32(int n, const void* const* depths, const void* const* imgs, int B, int H,
-                               int W, void* ws, float* out, void* stream);
+                               int W, void* ws, void* const* edges, float* out, void* stream);
 int scsfm_smooth_multi_bwd_f32(int n, const void* const* depths, const void* const* imgs, int B, int H,
-                               int W, void* ws, const float* g_loss, void* const* g_depths,
-                               void* stream);
+                               int W, void* ws, void* const* edges, const float* g_loss,
+                               void* const* g_depths, void* stream);
 int scsfm_smooth_multi_fwd_f64(int n, const void* const* depths, const void* const* imgs, int B, int H,
-                               int W, void* ws, double* out, void* stream);
+                               int W, void* ws, void* const* edges, double* out, void* stream);
 int scsfm_smooth_multi_bwd_f64(int n, const void* const* depths, const void* const* imgs, int B, int H,
-                               int W, void* ws, const double* g_loss, void* const* g_depths,
-                               void* stream);
+                               int W, void* ws, void* const* edges, const double* g_loss,
+                               void* const* g_depths, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The training input transform on the device (train.py:95-100; custom_transforms.py:33-84):

@@ -36,6 +36,8 @@ inline SmoothWs smooth_ws_layout(int B, int H, int W) {
 template <typename T>
 struct SmoothFrame {
   const T* depth; const T* img; double* per_img; double* partials; T* out; T* g_depth;
+  T* edge;  // optional plane [B,H,W]: sum over the pixel's four edges of +-sgn(dD) w / cnt, written by the
+            // forward so that the backward is a pure stream (no image reads, no exp)
 };
 template <typename T>
 struct SmoothBatch {
@@ -75,10 +77,17 @@ __global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(SmoothBatch<T> sb,
   const unsigned plane = unsigned(H) * unsigned(W);
   const T* __restrict__ depth = fr.depth + (size_t)b * plane;
   const T* __restrict__ img = fr.img + (size_t)b * 3 * plane;
+  T* __restrict__ edge = fr.edge ? fr.edge + (size_t)b * plane : nullptr;
   const bool in_x = x < W;
   const int xc = in_x ? x : W - 1;
+  const T icx = T(1.0 / ((double)B * H * (W - 1))), icy = T(1.0 / ((double)B * (H - 1) * W));
   T sd = T(0), sx = T(0), sy = T(0);
   Px<T> cur = load_px(depth, img, plane, unsigned(y0 < H ? y0 : H - 1) * unsigned(W) + unsigned(xc));
+  T ty_prev = T(0);  // lower edge of the row above the strip (only needed for the stored gradient terms)
+  if (edge && y0 > 0 && y0 < H) {
+    const Px<T> up = load_px(depth, img, plane, unsigned(y0 - 1) * unsigned(W) + unsigned(xc));
+    ty_prev = t_sgn(up.d - cur.d) * edge_weight(up, cur) * icy;
+  }
 #pragma unroll
   for (int r = 0; r < kSmRows; ++r) {
     const int y = y0 + r;
@@ -86,10 +95,24 @@ __global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(SmoothBatch<T> sb,
     Px<T> right = shfl_down_px(cur);  // every lane takes part
     if (lane == kWave - 1 && x + 1 < W) right = load_px(depth, img, plane, p + 1);
     const Px<T> down = load_px(depth, img, plane, unsigned(y + 1 < H ? y + 1 : H - 1) * unsigned(W) + unsigned(xc));
-    if (in_x && y < H) {
-      sd += cur.d;
-      if (x + 1 < W) sx += t_abs(cur.d - right.d) * edge_weight(cur, right);
-      if (y + 1 < H) sy += t_abs(cur.d - down.d) * edge_weight(cur, down);
+    const bool ex = in_x && y < H && x + 1 < W, ey = in_x && y < H && y + 1 < H;
+    const T wx = ex ? edge_weight(cur, right) : T(0), wy = ey ? edge_weight(cur, down) : T(0);
+    const T dx = cur.d - right.d, dy = cur.d - down.d;
+    if (in_x && y < H) sd += cur.d;
+    sx += t_abs(dx) * wx;
+    sy += t_abs(dy) * wy;
+    if (edge) {  // workgroup-uniform
+      const T tx = t_sgn(dx) * wx * icx, ty = t_sgn(dy) * wy * icy;
+      T tx_left = __shfl_up(tx, 1);
+      if (lane == 0) {
+        tx_left = T(0);
+        if (x > 0 && in_x && y < H) {
+          const Px<T> left = load_px(depth, img, plane, p - 1);
+          tx_left = t_sgn(left.d - cur.d) * edge_weight(left, cur) * icx;
+        }
+      }
+      if (in_x && y < H) edge[p] = tx - tx_left + ty - ty_prev;
+      ty_prev = ty;
     }
     cur = down;
   }
@@ -150,6 +173,19 @@ __global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(SmoothBatch<T> sb,
   const T iden = T(1.0 / fr.per_img[2 * b]);
   const T icx = T(1.0 / ((double)B * H * (W - 1))), icy = T(1.0 / ((double)B * (H - 1) * W));
   const T mean_term = T(fr.per_img[2 * b + 1] / (fr.per_img[2 * b] * fr.per_img[2 * b] * (double)H * W));
+  if (fr.edge) {  // the forward left the per-pixel edge terms: 4 B read + 8 B read-modify-write per pixel
+    const T* __restrict__ edge = fr.edge + (size_t)b * plane;
+    if (in_x) {
+#pragma unroll
+      for (int r = 0; r < kSmRows; ++r) {
+        const int y = y0 + r;
+        if (y >= H) break;
+        const unsigned p = unsigned(y) * unsigned(W) + unsigned(x);
+        g_depth[p] += g * (edge[p] * iden - mean_term);
+      }
+    }
+    return;
+  }
   Px<T> cur = load_px(depth, img, plane, unsigned(y0 < H ? y0 : H - 1) * unsigned(W) + unsigned(xc));
   // lower edge of the row above the strip
   T ty_prev = T(0);
@@ -182,19 +218,20 @@ __global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(SmoothBatch<T> sb,
 }
 
 template <typename T>
-static SmoothFrame<T> make_frame(int B, int H, int W, const void* depth, const void* img, void* ws, T* out, void* g_depth) {
+static SmoothFrame<T> make_frame(int B, int H, int W, const void* depth, const void* img, void* ws, T* out, void* g_depth,
+                                 void* edge) {
   const SmoothWs l = smooth_ws_layout(B, H, W);
   SmoothFrame<T> f;
   f.depth = (const T*)depth; f.img = (const T*)img;
   f.per_img = reinterpret_cast<double*>((char*)ws + l.off_img);
   f.partials = reinterpret_cast<double*>((char*)ws + l.off_partials);
-  f.out = out; f.g_depth = (T*)g_depth;
+  f.out = out; f.g_depth = (T*)g_depth; f.edge = (T*)edge;
   return f;
 }
 
 template <typename T>
 static int smooth_multi_fwd(int n, const void* const* depths, const void* const* imgs, int B, int H, int W, void* ws,
-                            T* out, void* stream_) {
+                            void* const* edges, T* out, void* stream_) {
   clear_status();
   if (n < 0 || B <= 0 || H < 2 || W < 2 || (n > 0 && (!depths || !imgs || !ws || !out))) return SCSFM_ERR_ARG;
   for (int i = 0; i < n; ++i)
@@ -206,7 +243,7 @@ static int smooth_multi_fwd(int n, const void* const* depths, const void* const*
     SmoothBatch<T> sb;
     for (int i = 0; i < m; ++i)
       sb.f[i] = make_frame<T>(B, H, W, depths[i0 + i], imgs[i0 + i], (char*)ws + (size_t)(i0 + i) * l.total, out + i0 + i,
-                              nullptr);
+                              nullptr, edges ? edges[i0 + i] : nullptr);
     hipLaunchKernelGGL((smooth_fwd_kernel<T>), dim3(l.nbx, l.nby, m * B), dim3(kThreads), 0, stream, sb, B, H, W);
     hipLaunchKernelGGL((smooth_finalize_kernel<T>), dim3(m), dim3(kThreads), 0, stream, sb, B, H, W, l.nbx * l.nby);
   }
@@ -215,7 +252,7 @@ static int smooth_multi_fwd(int n, const void* const* depths, const void* const*
 
 template <typename T>
 static int smooth_multi_bwd(int n, const void* const* depths, const void* const* imgs, int B, int H, int W, void* ws,
-                            const T* g_loss, void* const* g_depths, void* stream_) {
+                            void* const* edges, const T* g_loss, void* const* g_depths, void* stream_) {
   clear_status();
   if (n < 0 || B <= 0 || H < 2 || W < 2 || (n > 0 && (!depths || !imgs || !ws || !g_loss || !g_depths)))
     return SCSFM_ERR_ARG;
@@ -228,7 +265,7 @@ static int smooth_multi_bwd(int n, const void* const* depths, const void* const*
     SmoothBatch<T> sb;
     for (int i = 0; i < m; ++i)
       sb.f[i] = make_frame<T>(B, H, W, depths[i0 + i], imgs[i0 + i], (char*)ws + (size_t)(i0 + i) * l.total, nullptr,
-                              g_depths[i0 + i]);
+                              g_depths[i0 + i], edges ? edges[i0 + i] : nullptr);
     hipLaunchKernelGGL((smooth_bwd_kernel<T>), dim3(l.nbx, l.nby, m * B), dim3(kThreads), 0, stream, sb, B, H, W,
                        g_loss);
   }
@@ -246,23 +283,24 @@ size_t scsfm_smooth_ws_bytes(int B, int H, int W) {
 
 #define SCSFM_SMOOTH_API(SUF, T)                                                                                     \
   int scsfm_smooth_multi_fwd_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,   \
-                                   void* ws, T* out, void* stream) {                                                 \
-    return scsfm::smooth_multi_fwd<T>(n, depths, imgs, B, H, W, ws, out, stream);                                    \
+                                   void* ws, void* const* edges, T* out, void* stream) {                             \
+    return scsfm::smooth_multi_fwd<T>(n, depths, imgs, B, H, W, ws, edges, out, stream);                             \
   }                                                                                                                  \
   int scsfm_smooth_multi_bwd_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,   \
-                                   void* ws, const T* g_loss, void* const* g_depths, void* stream) {                 \
-    return scsfm::smooth_multi_bwd<T>(n, depths, imgs, B, H, W, ws, g_loss, g_depths, stream);                       \
+                                   void* ws, void* const* edges, const T* g_loss, void* const* g_depths,             \
+                                   void* stream) {                                                                   \
+    return scsfm::smooth_multi_bwd<T>(n, depths, imgs, B, H, W, ws, edges, g_loss, g_depths, stream);                \
   }                                                                                                                  \
   int scsfm_smooth_fwd_##SUF(int B, int H, int W, const T* depth, const T* img, void* ws, T* out, void* stream) {    \
     const void* d = depth; const void* im = img;                                                                     \
     if (!depth || !img) return SCSFM_ERR_ARG;                                                                        \
-    return scsfm::smooth_multi_fwd<T>(1, &d, &im, B, H, W, ws, out, stream);                                         \
+    return scsfm::smooth_multi_fwd<T>(1, &d, &im, B, H, W, ws, nullptr, out, stream);                                \
   }                                                                                                                  \
   int scsfm_smooth_bwd_##SUF(int B, int H, int W, const T* depth, const T* img, void* ws, const T* g_loss,           \
                              T* g_depth, void* stream) {                                                             \
     const void* d = depth; const void* im = img; void* g = g_depth;                                                  \
     if (!depth || !img || !g_depth) return SCSFM_ERR_ARG;                                                            \
-    return scsfm::smooth_multi_bwd<T>(1, &d, &im, B, H, W, ws, g_loss, &g, stream);                                  \
+    return scsfm::smooth_multi_bwd<T>(1, &d, &im, B, H, W, ws, nullptr, g_loss, &g, stream);                         \
   }
 
 SCSFM_SMOOTH_API(f32, float)

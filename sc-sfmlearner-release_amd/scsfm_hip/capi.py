@@ -357,18 +357,23 @@ def _ptr_array(tensors):
     return arr
 
 
-def smooth_multi_fwd(lib, depths, imgs):
-    """compute_smooth_loss (loss_functions.py:154-159): sum over frames -> (loss, ws)."""
+def smooth_multi_fwd(lib, depths, imgs, keep_edges=True):
+    """compute_smooth_loss (loss_functions.py:154-159): sum over frames -> (loss, ws).  With
+    ``keep_edges`` the forward also leaves every pixel's summed edge terms behind ``ws`` (one fp plane per
+    frame) and the backward becomes a pure stream."""
     _chk(*depths, *imgs)
     B, _, H, W = imgs[0].shape
     n = len(depths)
     for d, im in zip(depths, imgs):
         check_sizes(d, "depth", (B, 1, H, W))
         check_sizes(im, "img", (B, 3, H, W))
-    ws = torch.empty(n * _sizes(lib, B, H, W)[2], dtype=torch.uint8, device=imgs[0].device)
+    ws_bytes = _sizes(lib, B, H, W)[2]
+    plane_bytes = ((B * H * W * imgs[0].element_size() + 255) // 256) * 256 if keep_edges else 0
+    ws = torch.empty(n * (ws_bytes + plane_bytes), dtype=torch.uint8, device=imgs[0].device)
     outs = torch.empty(n, dtype=imgs[0].dtype, device=imgs[0].device)
+    edges = (_ct.c_void_p * n)(*[ws.data_ptr() + n * ws_bytes + i * plane_bytes for i in range(n)]) if keep_edges else None
     lib.call(f"scsfm_smooth_multi_fwd_{_suffix(imgs[0])}", n, _ptr_array(depths), _ptr_array(imgs), B, H, W, _p(ws),
-             _p(outs), _stream(imgs[0]))
+             edges, _p(outs), _stream(imgs[0]))
     return outs.sum(), ws
 
 
@@ -376,8 +381,12 @@ def smooth_multi_bwd(lib, depths, imgs, ws, g_loss, need=None):
     """-> list of dL/d depth (None where ``need[i]`` is False)."""
     B, _, H, W = imgs[0].shape
     n = len(depths)
+    ws_bytes = _sizes(lib, B, H, W)[2]
+    plane_bytes = ((B * H * W * imgs[0].element_size() + 255) // 256) * 256
+    has_edges = ws.numel() == n * (ws_bytes + plane_bytes)
+    edges = (_ct.c_void_p * n)(*[ws.data_ptr() + n * ws_bytes + i * plane_bytes for i in range(n)]) if has_edges else None
     g_all = torch.zeros((n,) + tuple(depths[0].shape), dtype=depths[0].dtype, device=depths[0].device)
     grads = [g_all[i] if (need is None or need[i]) else None for i in range(n)]
     lib.call(f"scsfm_smooth_multi_bwd_{_suffix(imgs[0])}", n, _ptr_array(depths), _ptr_array(imgs), B, H, W, _p(ws),
-             _p(g_loss), _ptr_array(grads), _stream(imgs[0]))
+             edges, _p(g_loss), _ptr_array(grads), _stream(imgs[0]))
     return grads

@@ -127,7 +127,7 @@ class SmoothLoss(torch.autograd.Function):
         rest = [_c(t) for t in rest]
         _need_cuda(*rest)
         depths, imgs = rest[:n], rest[n:]
-        loss, ws = capi.smooth_multi_fwd(lib, depths, imgs)
+        loss, ws = capi.smooth_multi_fwd(lib, depths, imgs, keep_edges=any(ctx.needs_input_grad[1:1 + n]))
         ctx.n = n
         ctx.save_for_backward(*rest, ws)
         return loss
