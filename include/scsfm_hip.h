@@ -43,6 +43,7 @@ extern "C" {
 #define SCSFM_DEBUG_X2 2048u  /* no dense accumulate into g_tgt_depth */
 #define SCSFM_DEBUG_X3 4096u  /* no 12-value block reduction / gP atomics */
 #define SCSFM_DEBUG_X4 8192u  /* no colour-tap gathers */
+#define SCSFM_DEBUG_X5 32768u /* scatter into the LDS window but never flush it */
 
 #define SCSFM_DEBUG_KERNEL_ONLY 16384u /* scsfm_pairs_fwd only, for timing: launch the main kernel alone (the
                                           constants of an earlier identical call are still in `ws`) */

@@ -85,16 +85,52 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// Wave sums of N values per lane with ~N + log2(64) shuffles instead of 6 N: at every butterfly step the
+// values are paired and each half of the exchanging lanes keeps one value of a pair (an odd value out
+// does the plain butterfly), so the live values halve as the lane sets do.  Afterwards v[0] of a lane
+// holds the complete sum of ONE of the original values: its index is returned, and `lead` says whether
+// this lane is the one that should publish it.  Every value meets exactly the addends of wave_sum()
+// in the same pairing, so the sums are bit-identical to wave_sum()'s.
+template <int N, typename T>
+__device__ __forceinline__ int wave_sum_packed(T (&v)[N], bool& lead) {
+  const int lane = threadIdx.x & (kWave - 1);
+  int n = N;
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    const bool up = (lane & o) != 0;
+#pragma unroll
+    for (int j = 0; j < n / 2; ++j) {
+      const T send = up ? v[2 * j] : v[2 * j + 1], keep = up ? v[2 * j + 1] : v[2 * j];
+      v[j] = keep + __shfl_xor(send, o);
+    }
+    if (n & 1) v[n / 2] = v[n - 1] + __shfl_xor(v[n - 1], o);
+    n = (n + 1) / 2;
+  }
+  // walk the steps backwards from slot 0 to the original index; steps that did not split leave their
+  // lane bit free (all those lanes hold the same sum)
+  int cnt[7];
+  cnt[0] = N;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) cnt[s + 1] = (cnt[s] + 1) / 2;
+  int slot = 0, free_bits = 0;
+#pragma unroll
+  for (int s = 5; s >= 0; --s) {
+    const int o = (kWave / 2) >> s, half = cnt[s] / 2;
+    if (slot < half) slot = 2 * slot + ((lane & o) ? 1 : 0);  // came from a pair: the lane bit says which
+    else { slot = cnt[s] - 1; free_bits |= o; }                // the odd value out: both lane halves hold it
+  }
+  lead = (lane & free_bits) == 0;
+  return slot;
+}
+
 // Sum N values per thread over the whole block; the result replaces v[] in thread 0 (other threads
-// keep their own partial values).  `scratch` must hold N * (kThreads / kWave) doubles.
+// keep partial values).  `scratch` must hold N * (kThreads / kWave) doubles.
 template <int N, typename T>
 __device__ __forceinline__ void block_sum(T (&v)[N], double* scratch) {
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const T s = wave_sum(v[i]);
-    if (lane == 0) scratch[wave * N + i] = double(s);
-  }
+  const int wave = threadIdx.x / kWave;
+  bool lead;
+  const int idx = wave_sum_packed<N>(v, lead);
+  if (lead) scratch[wave * N + idx] = double(v[0]);
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
@@ -133,9 +169,14 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
   return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 
-template <typename T> __device__ __forceinline__ T t_abs(T x) { return x < T(0) ? -x : x; }
-template <typename T> __device__ __forceinline__ T t_min(T a, T b) { return a < b ? a : b; }
-template <typename T> __device__ __forceinline__ T t_max(T a, T b) { return a > b ? a : b; }
+// fabs / fmin / fmax builtins: |x| is a free source modifier and min / max are single instructions on
+// gfx950 (the ternary forms compile to compare + select because of their -0 / NaN corner cases)
+__device__ __forceinline__ float t_abs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double t_abs(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float t_min(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double t_min(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float t_max(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double t_max(double a, double b) { return __builtin_fmax(a, b); }
 template <typename T> __device__ __forceinline__ T t_sgn(T x) { return x > T(0) ? T(1) : (x < T(0) ? T(-1) : T(0)); }
 __device__ __forceinline__ float t_floor(float x) { return floorf(x); }
 __device__ __forceinline__ double t_floor(double x) { return floor(x); }
@@ -143,6 +184,18 @@ __device__ __forceinline__ float t_exp(float x) { return expf(x); }
 __device__ __forceinline__ double t_exp(double x) { return exp(x); }
 __device__ __forceinline__ void t_sincos(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
 __device__ __forceinline__ void t_sincos(double x, double* s, double* c) { *s = sin(x); *c = cos(x); }
+// Load at a 32-bit byte offset from a wave-uniform base: compiles to the scalar-base addressing mode
+// (global_load ... v_off, s[base:base+1]) with no 64-bit vector address arithmetic.  Every plane this
+// library indexes that way is far below 4 GiB (checked on the host side).
+template <typename T>
+__device__ __forceinline__ T ld_at(const T* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void st_at(T* __restrict__ base, unsigned byte_off, T v) {
+  *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 // reciprocal: v_rcp_f32 (1 ulp) on the fp32 product path, exact division for the fp64 check path
 __device__ __forceinline__ float t_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double t_rcp(double x) { return 1.0 / x; }

@@ -172,6 +172,8 @@ struct Sample {
   unsigned offr[2]; // element offset of the (west, east) tap PAIR of the north / south row: the west column is
                     // clamped to [0, W-2] so that one 8-byte load fetches both taps of a row
   int xsel;         // x0 - clamped west column: -1 / 0 / +1 tells which half of the pair is which tap
+  T wp[4];          // the bilinear weights re-addressed to the loaded pairs (north.a, north.b, south.a, south.b):
+                    // equal to w[] except where the pair was shifted at the left / right image border
   unsigned inb;     // bit k: tap k lies inside the image
   int x0, y0;       // north-west tap (unclamped)
   bool valid;       // max(|xn|, |yn|) <= 1   (inverse_warp.py:264)
@@ -234,6 +236,11 @@ __device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int
   const int xa = t_clampi(x0, 0, W - 2);
   s.offr[0] = unsigned(r0 + xa); s.offr[1] = unsigned(r1 + xa);
   s.xsel = x0 - xa;
+  // xsel = -1: the pair is (I[0], I[1]) and only its first half is a tap (the east one); xsel = +1: the
+  // pair is (I[W-2], I[W-1]) and only its second half is a tap (the west one)
+  const T wxa = s.xsel == 1 ? T(0) : (s.xsel == -1 ? wx1 : wx0);
+  const T wxb = s.xsel == -1 ? T(0) : (s.xsel == 1 ? wx0 : wx1);
+  s.wp[0] = wy0 * wxa; s.wp[1] = wy0 * wxb; s.wp[2] = wy1 * wxa; s.wp[3] = wy1 * wxb;
   return s;
 }
 
@@ -244,9 +251,24 @@ __device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int
 template <typename T>
 struct TapPair { T a, b; };
 template <typename T>
+struct TapRows { TapPair<T> n, s; };
+template <typename T>
+__device__ __forceinline__ TapRows<T> load_tap_rows(const T* __restrict__ plane, const Sample<T>& s) {
+  TapRows<T> r;
+  r.n = ld_at(reinterpret_cast<const TapPair<T>*>(plane), s.offr[0] * unsigned(sizeof(T)));
+  r.s = ld_at(reinterpret_cast<const TapPair<T>*>(plane), s.offr[1] * unsigned(sizeof(T)));
+  return r;
+}
+// The sampled value straight from the pairs (no re-ordering of the data: the weights were re-addressed).
+template <typename T>
+__device__ __forceinline__ T bilerp_rows(const TapRows<T>& r, const Sample<T>& s) {
+  return r.n.a * s.wp[0] + r.n.b * s.wp[1] + r.s.a * s.wp[2] + r.s.b * s.wp[3];
+}
+// The four taps in tap order (the backward needs the values themselves).
+template <typename T>
 __device__ __forceinline__ void load_taps(const T* __restrict__ plane, const Sample<T>& s, T* v) {
-  const TapPair<T> n = *reinterpret_cast<const TapPair<T>*>(plane + s.offr[0]);
-  const TapPair<T> so = *reinterpret_cast<const TapPair<T>*>(plane + s.offr[1]);
+  const TapRows<T> r = load_tap_rows(plane, s);
+  const TapPair<T> n = r.n, so = r.s;
   v[0] = s.xsel == 1 ? n.b : n.a;  v[1] = s.xsel == -1 ? n.a : n.b;
   v[2] = s.xsel == 1 ? so.b : so.a; v[3] = s.xsel == -1 ? so.a : so.b;
 }
@@ -317,7 +339,11 @@ __device__ __forceinline__ void scatter_taps(T* __restrict__ gplane, const Sampl
 // lands (motion is locally coherent): taps inside the window are LDS atomics, the rest fall back to
 // global atomics.  The window is flushed once per block with coalesced atomics (flush_scatter_window),
 // which cuts the device-scope atomic traffic from 4 per source pixel to ~1 per touched destination.
-constexpr int kWinW = 96, kWinH = 32;
+#ifndef SCSFM_WIN_W  // tuning knobs (tools/build_variants.sh); the defaults are the product
+#define SCSFM_WIN_W 96
+#define SCSFM_WIN_H 32
+#endif
+constexpr int kWinW = SCSFM_WIN_W, kWinH = SCSFM_WIN_H;
 
 template <typename T>
 __device__ __forceinline__ void scatter_taps_window(T (*win)[kWinW], int wx0, int wy0, T* __restrict__ gplane,

@@ -37,19 +37,34 @@ struct PairBatch {
   PairArgs<T> p[kMaxPairs];
 };
 
-// Warp one pixel (already reflected into the image): the (target, warped) colour pairs.
+// The streaming inputs of one pixel (already reflected into the image): depth, target colours and -- for
+// the auto-mask -- the un-warped reference colours.  They are loaded for a thread's whole strip before
+// anything else, so that a single memory round trip precedes the dependent gathers.
 template <typename T>
-__device__ __forceinline__ Sample<T> warp_colours(const BatchConsts<T>& bc, int u, int v, int H, int W, unsigned flags,
-                                                  const T* __restrict__ tgt_img, const T* __restrict__ ref_img,
-                                                  const T* __restrict__ tgt_depth, typename Vec2<T>::type* xy) {
-  const unsigned plane = unsigned(H) * unsigned(W), p = unsigned(v) * unsigned(W) + unsigned(u);
-  const Sample<T> s = project_pixel(bc, u, v, tgt_depth[p], H, W, flags);
-  T t[4];
+__device__ __forceinline__ void load_pixel(int u, int v, int W, unsigned plane, const T* __restrict__ tgt_img,
+                                           const T* __restrict__ ref_img, const T* __restrict__ tgt_depth,
+                                           bool with_ref, T& depth, T (&tgt)[3], T (&ref)[3]) {
+  const unsigned off = (unsigned(v) * unsigned(W) + unsigned(u)) * unsigned(sizeof(T));
+  depth = ld_at(tgt_depth, off);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    load_taps(ref_img + c * plane, s, t);
-    xy[c] = make2(tgt_img[c * plane + p], bilerp(t, s));
+  for (int c = 0; c < 3; ++c) tgt[c] = ld_at(tgt_img + c * plane, off);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ref[c] = T(0);
+  if (with_ref) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ref[c] = ld_at(ref_img + c * plane, off);
   }
+}
+
+// Warp one pixel: the (target, warped) colour pairs.
+template <typename T>
+__device__ __forceinline__ Sample<T> warp_colours(const BatchConsts<T>& bc, int u, int v, T depth, const T (&tgt)[3],
+                                                  int H, int W, unsigned flags, const T* __restrict__ ref_img,
+                                                  typename Vec2<T>::type* xy) {
+  const unsigned plane = unsigned(H) * unsigned(W);
+  const Sample<T> s = project_pixel(bc, u, v, depth, H, W, flags);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) xy[c] = make2(tgt[c], bilerp_rows(load_tap_rows(ref_img + c * plane, s), s));
   return s;
 }
 
@@ -67,11 +82,10 @@ __global__ void pairs_prep_kernel(PairBatch<T> pb, int n, int B, const T* __rest
 // Both means share the divisor 3, so the sums are compared.
 template <typename T>
 __device__ __forceinline__ T pixel_mask(const Sample<T>& s, bool with_auto, const typename Vec2<T>::type* xy,
-                                        const T* __restrict__ ref_img, unsigned plane, unsigned p) {
+                                        const T (&ref)[3]) {
   T m = s.valid ? T(1) : T(0);
   if (with_auto) {
-    const T ident = t_abs(xy[0][0] - ref_img[p]) + t_abs(xy[1][0] - ref_img[plane + p]) +
-                    t_abs(xy[2][0] - ref_img[2 * plane + p]);
+    const T ident = t_abs(xy[0][0] - ref[0]) + t_abs(xy[1][0] - ref[1]) + t_abs(xy[2][0] - ref[2]);
     const T warped = clamp01(t_abs(xy[0][0] - xy[0][1])) + clamp01(t_abs(xy[1][0] - xy[1][1])) +
                      clamp01(t_abs(xy[2][0] - xy[2][1]));
     m = (warped < ident) ? m : T(0);
@@ -109,36 +123,45 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(PairBatch<T> pb, int
   ref_depth += (size_t)b * plane;
 
   T m[STRIP], dd[STRIP], l1sum[STRIP];
+  // ---- phase 0: every streaming load of the strip and of this thread's ring pixel ---------------
+  const int gx = tx0 + col, u = reflect_index(gx, W);
+  T in_d[STRIP], in_t[STRIP][3], in_r[STRIP][3], rin_d = T(0), rin_t[3] = {T(0), T(0), T(0)}, rin_r[3];
+#pragma unroll
+  for (int k = 0; k < STRIP; ++k)
+    load_pixel(u, reflect_index(ty0 + strip * STRIP + k, H), W, plane, tgt_img, ref_img, tgt_depth, with_auto, in_d[k],
+               in_t[k], in_r[k]);
+  const bool has_ring = kSsim && threadIdx.x < 2 * kHaloW + 2 * TH;
+  int ru = 0, rv = 0, rhy = 0, rhx = 0;
+  if (has_ring) {
+    ring_pos<TH>(threadIdx.x, rhy, rhx);
+    ru = reflect_index(tx0 + rhx - 1, W); rv = reflect_index(ty0 + rhy - 1, H);
+    load_pixel(ru, rv, W, plane, tgt_img, ref_img, tgt_depth, false, rin_d, rin_t, rin_r);
+  }
   // ---- phase 1a: the pixels this thread owns -------------------------------------------------
 #pragma unroll
   for (int k = 0; k < STRIP; ++k) {
-    const int ly = strip * STRIP + k, gx = tx0 + col, gy = ty0 + ly;
+    const int ly = strip * STRIP + k, gy = ty0 + ly;
     const bool inimg = gx < W && gy < H;
-    const int u = reflect_index(gx, W), v = reflect_index(gy, H);
+    const int v = reflect_index(gy, H);
     V2 xy[3];
-    const Sample<T> s = warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, xy);
+    const Sample<T> s = warp_colours(bc, u, v, in_d[k], in_t[k], H, W, flags, ref_img, xy);
     if (kSsim) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) sXY[c][ly + 1][col + 1] = xy[c];
     }
     l1sum[k] = clamp01(t_abs(xy[0][0] - xy[0][1])) + clamp01(t_abs(xy[1][0] - xy[1][1])) +
                clamp01(t_abs(xy[2][0] - xy[2][1]));  // loss_functions.py:99, summed over colours
-    T t[4];
-    load_taps(ref_depth, s, t);
-    const T Dp = bilerp(t, s);
+    const T Dp = bilerp_rows(load_tap_rows(ref_depth, s), s);
     dd[k] = clamp01(t_abs(s.Z - Dp) * t_rcp(s.Z + Dp));  // loss_functions.py:101
-    m[k] = inimg ? pixel_mask(s, with_auto, xy, ref_img, plane, unsigned(v) * unsigned(W) + unsigned(u)) : T(0);
+    m[k] = inimg ? pixel_mask(s, with_auto, xy, in_r[k]) : T(0);
   }
   // ---- phase 1b: the 1-pixel ring (SSIM windows of the tile's border pixels) ------------------
   if (kSsim) {
-    if (threadIdx.x < 2 * kHaloW + 2 * TH) {
-      int hy, hx;
-      ring_pos<TH>(threadIdx.x, hy, hx);
-      const int u = reflect_index(tx0 + hx - 1, W), v = reflect_index(ty0 + hy - 1, H);
+    if (has_ring) {
       V2 xy[3];
-      warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, xy);
+      warp_colours(bc, ru, rv, rin_d, rin_t, H, W, flags, ref_img, xy);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) sXY[c][hy][hx] = xy[c];
+      for (int c = 0; c < 3; ++c) sXY[c][rhy][rhx] = xy[c];
     }
     __syncthreads();
   }
@@ -247,8 +270,11 @@ __device__ __forceinline__ bool spec_valid(const double* __restrict__ sums, cons
   return double(g_geom[0]) * gate_g * sums[9] == double(g_photo[0]) * sums[10];  // products of floats: exact
 }
 
+#ifndef SCSFM_PHOTO_BLOCKS  // tuning knob (tools/build_variants.sh): workgroups per CU the tiled pass is compiled for
+#define SCSFM_PHOTO_BLOCKS 3
+#endif
 template <typename T, bool kSsim, bool kSpec>
-__global__ __launch_bounds__(kThreads, 3) void pair_bwd_photo_kernel(
+__global__ __launch_bounds__(kThreads, SCSFM_PHOTO_BLOCKS) void pair_bwd_photo_kernel(
     PairBatch<T> pb, int B, int H, int W, unsigned flags, const T* __restrict__ g_photo,
     const T* __restrict__ g_geom, T r_hint) {
   const BlockId blk = xcd_block_id();
@@ -297,23 +323,35 @@ __global__ __launch_bounds__(kThreads, 3) void pair_bwd_photo_kernel(
   T bsum[STRIP];  // sum_c blend_c of the owned pixel
   T acc_g = T(0), acc_m = T(0);  // kSpec: forward sums over the pixels this block owns
   V2 cen[kSsim ? 1 : STRIP][kSsim ? 1 : 3];
+  // ---- phase 0: every streaming load of the strip and of this thread's ring pixel ---------------
+  const int u = reflect_index(px, W);
+  T in_d[STRIP], in_t[STRIP][3], in_r[STRIP][3], rin_d = T(0), rin_t[3] = {T(0), T(0), T(0)}, rin_r[3];
+#pragma unroll
+  for (int k = 0; k < STRIP; ++k)
+    load_pixel(u, reflect_index(py0 + k, H), W, plane, tgt_img, ref_img, tgt_depth, with_auto, in_d[k], in_t[k],
+               in_r[k]);
+  const bool has_ring = kSsim && threadIdx.x < 2 * kHaloW + 2 * TH;
+  int ru = 0, rv = 0, rhy = 0, rhx = 0;
+  if (has_ring) {
+    ring_pos<TH>(threadIdx.x, rhy, rhx);
+    ru = reflect_index(ox + rhx - 1, W); rv = reflect_index(oy + rhy - 1, H);
+    load_pixel(ru, rv, W, plane, tgt_img, ref_img, tgt_depth, false, rin_d, rin_t, rin_r);
+  }
   // ---- phase 1a ------------------------------------------------------------------------------
 #pragma unroll
   for (int k = 0; k < STRIP; ++k) {
     const int ly = strip * STRIP + k, py = py0 + k;
     const bool inimg = px >= 0 && px < W && py >= 0 && py < H;
-    const int u = reflect_index(px, W), v = reflect_index(py, H);
+    const int v = reflect_index(py, H);
     V2 xy[3];
-    const Sample<T> s = warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, xy);
+    const Sample<T> s = warp_colours(bc, u, v, in_d[k], in_t[k], H, W, flags, ref_img, xy);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       if constexpr (kSsim) sXY[c][ly + 1][col + 1] = xy[c]; else cen[k][c] = xy[c];
     }
-    T t[4];
-    load_taps(ref_depth, s, t);
-    const T Dp = bilerp(t, s);
+    const T Dp = bilerp_rows(load_tap_rows(ref_depth, s), s);
     const T ddk = clamp01(t_abs(s.Z - Dp) * t_rcp(s.Z + Dp));
-    mq[k] = inimg ? pixel_mask(s, with_auto, xy, ref_img, plane, unsigned(v) * unsigned(W) + unsigned(u)) : T(0);
+    mq[k] = inimg ? pixel_mask(s, with_auto, xy, in_r[k]) : T(0);
     coef[k] = a * mq[k] * (with_mask ? (T(1) - ddk) : T(1));
     bsum[k] = T(0);
     if constexpr (kSpec) {
@@ -322,14 +360,11 @@ __global__ __launch_bounds__(kThreads, 3) void pair_bwd_photo_kernel(
   }
   // ---- phase 1b: ring ------------------------------------------------------------------------
   if constexpr (kSsim) {
-    if (threadIdx.x < 2 * kHaloW + 2 * TH) {
-      int hy, hx;
-      ring_pos<TH>(threadIdx.x, hy, hx);
-      const int u = reflect_index(ox + hx - 1, W), v = reflect_index(oy + hy - 1, H);
+    if (has_ring) {
       V2 xy[3];
-      warp_colours(bc, u, v, H, W, flags, tgt_img, ref_img, tgt_depth, xy);
+      warp_colours(bc, ru, rv, rin_d, rin_t, H, W, flags, ref_img, xy);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) sXY[c][hy][hx] = xy[c];
+      for (int c = 0; c < 3; ++c) sXY[c][rhy][rhx] = xy[c];
     }
     __syncthreads();
   }
@@ -378,7 +413,8 @@ __global__ __launch_bounds__(kThreads, 3) void pair_bwd_photo_kernel(
     for (int k = 0; k < STRIP; ++k) {
       const int ly = strip * STRIP + k, py = py0 + k;
       // note: m(p) = 0 still receives SSIM gradient through its neighbours' windows
-      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) gbuf[c * gplane + unsigned(py) * unsigned(W) + unsigned(px)] = gI[k];
+      if (in_x && ly >= 1 && ly <= TH - 2 && py < H)
+        st_at(gbuf + c * gplane, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gI[k]);
     }
   }
   // dL/d diff_depth: directly (geometry loss) and through the weight mask (no detach, loss_functions.py:111-113)
@@ -386,8 +422,8 @@ __global__ __launch_bounds__(kThreads, 3) void pair_bwd_photo_kernel(
   for (int k = 0; k < STRIP; ++k) {
     const int ly = strip * STRIP + k, py = py0 + k;
     if (in_x && ly >= 1 && ly <= TH - 2 && py < H)
-      gbuf[3 * gplane + unsigned(py) * unsigned(W) + unsigned(px)] =
-          bg * mq[k] - (with_mask ? a * mq[k] * bsum[k] : T(0));
+      st_at(gbuf + 3 * gplane, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)),
+            bg * mq[k] - (with_mask ? a * mq[k] * bsum[k] : T(0)));
   }
   if constexpr (kSpec) {  // the forward's three sums over the pixels this block owns
     T v[3] = {T(0), acc_g, acc_m};
@@ -471,10 +507,10 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     const int py = py0 + r;
-    const unsigned p = unsigned(py < H ? py : H - 1) * unsigned(W) + unsigned(px < W ? px : W - 1);
-    in_d[r] = tgt_depth[p];
+    const unsigned p = (unsigned(py < H ? py : H - 1) * unsigned(W) + unsigned(px < W ? px : W - 1)) * unsigned(sizeof(T));
+    in_d[r] = ld_at(tgt_depth, p);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) in_g[r][c] = gbuf[c * gplane + p];
+    for (int c = 0; c < 4; ++c) in_g[r][c] = ld_at(gbuf + c * gplane, p);
   }
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
@@ -510,10 +546,10 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
     giy += gDp * dot4(t, sg.cy);
     if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window(win, wx0, wy0, g_ref_depth, s, gDp);
     const T gd = pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
-    g_tgt_depth[p] = (flags & SCSFM_DEBUG_X2) ? T(0) : gd;
+    st_at(g_tgt_depth, p * unsigned(sizeof(T)), (flags & SCSFM_DEBUG_X2) ? T(0) : gd);
   }
   __syncthreads();
-  if (!(flags & SCSFM_DEBUG_X1)) flush_scatter_window(win, wx0, wy0, g_ref_depth, W);
+  if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5))) flush_scatter_window(win, wx0, wy0, g_ref_depth, W);
   if (flags & SCSFM_DEBUG_X3) {  // profiling: keep the partials defined
     if (threadIdx.x == 0)
       for (int i = 0; i < 12; ++i) gP[12 * ((size_t)(b * gridDim.y + blk.y) * gridDim.x + blk.x) + i] = 0.0;

@@ -20,7 +20,8 @@ import torch  # noqa: F401  (must precede ctypes.CDLL below)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "scsfm_hip.h")
-LIB_PATH = os.path.join(HERE, "libscsfm_hip.so")
+# SCSFM_HIP_LIB points at a library built elsewhere (tuning variants, a system-wide install)
+LIB_PATH = os.environ.get("SCSFM_HIP_LIB") or os.path.join(HERE, "libscsfm_hip.so")
 
 _CTYPES = {"int": ctypes.c_int, "unsigned": ctypes.c_uint, "size_t": ctypes.c_size_t, "double": ctypes.c_double}
 _DECL = re.compile(r"^(int|size_t)\s+(scsfm_\w+)\s*\(([^)]*)\)\s*;", re.M | re.S)

@@ -18,7 +18,10 @@ CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 LIB = os.path.join(HERE, "libscsfm_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-munsafe-fp-atomics",
-         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         # the SLP vectoriser pairs unrelated scalar fp32 chains into v_pk_* with 4 v_mov per packed op (+5 % VALU
+         # in the tiled pass); the 2-wide math that pays is written with vector types in csrc/scsfm_ssim.h
+         "-fno-slp-vectorize"]
 
 
 def sources():
