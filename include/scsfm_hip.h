@@ -42,7 +42,7 @@ extern "C" {
 #define SCSFM_DEBUG_X1 1024u  /* no scatter into g_ref_depth (no LDS window, no atomics) */
 #define SCSFM_DEBUG_X2 2048u  /* no dense accumulate into g_tgt_depth */
 #define SCSFM_DEBUG_X3 4096u  /* no 12-value block reduction / gP atomics */
-#define SCSFM_DEBUG_X4 8192u  /* no colour-tap gathers */
+#define SCSFM_DEBUG_X4 8192u  /* unused (the colour taps moved into the tiled pass) */
 #define SCSFM_DEBUG_X5 32768u /* scatter into the LDS window but never flush it */
 
 #define SCSFM_DEBUG_KERNEL_ONLY 16384u /* scsfm_pairs_fwd only, for timing: launch the main kernel alone (the
@@ -235,10 +235,11 @@ int scsfm_masked_mean_bwd_f64(int B, int C, int Cm, int HW, const double* mask, 
 
 /* compute_smooth_loss (loss_functions.py:154-159): n frames per call.  depths / imgs / g_depths / edges
  * are HOST arrays of n DEVICE pointers; ws = n * scsfm_smooth_ws_bytes(B,H,W) bytes; out[n] (device,
- * store) holds one loss per frame; a NULL g_depths[i] skips that frame's gradient.
+ * store) holds one loss per frame; g_depths[i] is STORED (every pixel is written, no zero-fill needed;
+ * the single-frame scsfm_smooth_bwd accumulates); a NULL g_depths[i] skips that frame's gradient.
  * edges (may be NULL, as may any entry): per frame a [B,H,W] plane in which the forward leaves each
- * pixel's summed edge terms; given the same plane, the backward is a pure stream (4 B read + 8 B
- * read-modify-write per pixel) instead of re-evaluating the edge weights from the images. */
+ * pixel's summed edge terms; given the same plane, the backward is a pure stream (4 B read + 4 B
+ * written per pixel) instead of re-evaluating the edge weights from the images. */
 int scsfm_smooth_multi_fwd_f32(int n, const void* const* depths, const void* const* imgs, int B, int H,
                                int W, void* ws, void* const* edges, float* out, void* stream);
 int scsfm_smooth_multi_bwd_f32(int n, const void* const* depths, const void* const* imgs, int B, int H,

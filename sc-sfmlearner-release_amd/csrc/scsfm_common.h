@@ -182,6 +182,10 @@ __device__ __forceinline__ float t_floor(float x) { return floorf(x); }
 __device__ __forceinline__ double t_floor(double x) { return floor(x); }
 __device__ __forceinline__ float t_exp(float x) { return expf(x); }
 __device__ __forceinline__ double t_exp(double x) { return exp(x); }
+// exp of a small non-positive argument (edge weights): one v_exp_f32 after the log2(e) scaling, ~|x| 2^-24
+// relative error from the scaling + 1 ulp, instead of expf's ~12-instruction range reduction
+__device__ __forceinline__ float t_exp_weight(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ double t_exp_weight(double x) { return exp(x); }
 __device__ __forceinline__ void t_sincos(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
 __device__ __forceinline__ void t_sincos(double x, double* s, double* c) { *s = sin(x); *c = cos(x); }
 // Load at a 32-bit byte offset from a wave-uniform base: compiles to the scalar-base addressing mode

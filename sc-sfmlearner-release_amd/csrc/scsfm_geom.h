@@ -174,6 +174,10 @@ struct Sample {
   int xsel;         // x0 - clamped west column: -1 / 0 / +1 tells which half of the pair is which tap
   T wp[4];          // the bilinear weights re-addressed to the loaded pairs (north.a, north.b, south.a, south.b):
                     // equal to w[] except where the pair was shifted at the left / right image border
+  T wxa, wxb;       // ... their column factors (weight of the pair's first / second element)
+  T wy0, wy1;       // ... and row factors (north / south row; 0 for a row outside the image)
+  T sxa, sxb;       // d(column weight)/d ix of the pair's elements: -1 / +1 for a tap inside the image, else 0
+  T vy0, vy1;       // 1 if the north / south row lies inside the image
   unsigned inb;     // bit k: tap k lies inside the image
   int x0, y0;       // north-west tap (unclamped)
   bool valid;       // max(|xn|, |yn|) <= 1   (inverse_warp.py:264)
@@ -238,9 +242,14 @@ __device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int
   s.xsel = x0 - xa;
   // xsel = -1: the pair is (I[0], I[1]) and only its first half is a tap (the east one); xsel = +1: the
   // pair is (I[W-2], I[W-1]) and only its second half is a tap (the west one)
-  const T wxa = s.xsel == 1 ? T(0) : (s.xsel == -1 ? wx1 : wx0);
-  const T wxb = s.xsel == -1 ? T(0) : (s.xsel == 1 ? wx0 : wx1);
-  s.wp[0] = wy0 * wxa; s.wp[1] = wy0 * wxb; s.wp[2] = wy1 * wxa; s.wp[3] = wy1 * wxb;
+  const T mw = xw ? T(-1) : T(0), me = xe ? T(1) : T(0);
+  s.wxa = s.xsel == 1 ? T(0) : (s.xsel == -1 ? wx1 : wx0);
+  s.wxb = s.xsel == -1 ? T(0) : (s.xsel == 1 ? wx0 : wx1);
+  s.sxa = s.xsel == 1 ? T(0) : (s.xsel == -1 ? me : mw);
+  s.sxb = s.xsel == -1 ? T(0) : (s.xsel == 1 ? mw : me);
+  s.wy0 = wy0; s.wy1 = wy1;
+  s.vy0 = yn_ ? T(1) : T(0); s.vy1 = ys ? T(1) : T(0);
+  s.wp[0] = wy0 * s.wxa; s.wp[1] = wy0 * s.wxb; s.wp[2] = wy1 * s.wxa; s.wp[3] = wy1 * s.wxb;
   return s;
 }
 
@@ -263,6 +272,14 @@ __device__ __forceinline__ TapRows<T> load_tap_rows(const T* __restrict__ plane,
 template <typename T>
 __device__ __forceinline__ T bilerp_rows(const TapRows<T>& r, const Sample<T>& s) {
   return r.n.a * s.wp[0] + r.n.b * s.wp[1] + r.s.a * s.wp[2] + r.s.b * s.wp[3];
+}
+// d(sampled value)/d(ix, iy) from the pairs: out-of-image taps count as the value 0 and have no weight
+// (what grid_sampler_2d_backward does for the coordinate gradient).
+//   d/d ix = sum_rows wy * (east - west),  d/d iy = sum_cols wx * (south - north)
+template <typename T>
+__device__ __forceinline__ void tap_rows_grad(const TapRows<T>& r, const Sample<T>& s, T& dx, T& dy) {
+  dx = s.wy0 * (s.sxa * r.n.a + s.sxb * r.n.b) + s.wy1 * (s.sxa * r.s.a + s.sxb * r.s.b);
+  dy = s.vy1 * (s.wxa * r.s.a + s.wxb * r.s.b) - s.vy0 * (s.wxa * r.n.a + s.wxb * r.n.b);
 }
 // The four taps in tap order (the backward needs the values themselves).
 template <typename T>
@@ -344,6 +361,10 @@ __device__ __forceinline__ void scatter_taps(T* __restrict__ gplane, const Sampl
 #define SCSFM_WIN_H 32
 #endif
 constexpr int kWinW = SCSFM_WIN_W, kWinH = SCSFM_WIN_H;
+#ifndef SCSFM_GEOM_ROWS
+#define SCSFM_GEOM_ROWS 4
+#endif
+constexpr int kGeomRows = SCSFM_GEOM_ROWS;  // rows per thread of the geometry pass (its tile is 64 x 4 kGeomRows)
 
 template <typename T>
 __device__ __forceinline__ void scatter_taps_window(T (*win)[kWinW], int wx0, int wy0, T* __restrict__ gplane,
@@ -352,12 +373,18 @@ __device__ __forceinline__ void scatter_taps_window(T (*win)[kWinW], int wx0, in
   const int lx = s.x0 - wx0, ly = s.y0 - wy0;
   if (lx >= 0 && lx < kWinW - 1 && ly >= 0 && ly < kWinH - 1) {
     // unpredicated: an out-of-image tap has weight 0, and adding 0 leaves its cell at the 0 the flush skips
+#if defined(SCSFM_EXPERIMENT_PLAIN_LDS)
+    win[ly][lx] = g * s.w[0]; win[ly][lx + 1] = g * s.w[1]; win[ly + 1][lx] = g * s.w[2]; win[ly + 1][lx + 1] = g * s.w[3];
+#else
     atomicAdd(&win[ly][lx], g * s.w[0]);
     atomicAdd(&win[ly][lx + 1], g * s.w[1]);
     atomicAdd(&win[ly + 1][lx], g * s.w[2]);
     atomicAdd(&win[ly + 1][lx + 1], g * s.w[3]);
+#endif
   } else {
+#if !defined(SCSFM_EXPERIMENT_NO_FALLBACK)
     scatter_taps(gplane, s, g);
+#endif
   }
 }
 

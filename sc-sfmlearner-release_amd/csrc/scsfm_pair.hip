@@ -32,6 +32,11 @@ struct PairArgs {
   T* out; T* gbuf; T* g_ref_depth; T* g_pose;
 };
 constexpr int kMaxPairs = 8;
+// Planes of a pair's gbuf (each B x H x W): what the tiled pass hands to the geometry pass, and the geometry
+// pass's private dense output.
+constexpr int kPlaneGI = 0;     // planes 0..2: dL/d(warped colour c)
+constexpr int kPlaneGdd = 3;    // dL/d diff_depth
+constexpr int kPlaneDense = 4;  // dL/d tgt_depth of this pair-direction
 template <typename T>
 struct PairBatch {
   PairArgs<T> p[kMaxPairs];
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(kThreads, SCSFM_PHOTO_BLOCKS) void pair_bwd_photo_k
       const int ly = strip * STRIP + k, py = py0 + k;
       // note: m(p) = 0 still receives SSIM gradient through its neighbours' windows
       if (in_x && ly >= 1 && ly <= TH - 2 && py < H)
-        st_at(gbuf + c * gplane, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gI[k]);
+        st_at(gbuf + (kPlaneGI + c) * gplane, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gI[k]);
     }
   }
   // dL/d diff_depth: directly (geometry loss) and through the weight mask (no detach, loss_functions.py:111-113)
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(kThreads, SCSFM_PHOTO_BLOCKS) void pair_bwd_photo_k
   for (int k = 0; k < STRIP; ++k) {
     const int ly = strip * STRIP + k, py = py0 + k;
     if (in_x && ly >= 1 && ly <= TH - 2 && py < H)
-      st_at(gbuf + 3 * gplane, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)),
+      st_at(gbuf + kPlaneGdd * gplane, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)),
             bg * mq[k] - (with_mask ? a * mq[k] * bsum[k] : T(0)));
   }
   if constexpr (kSpec) {  // the forward's three sums over the pixels this block owns
@@ -447,8 +452,11 @@ __global__ __launch_bounds__(kThreads, SCSFM_PHOTO_BLOCKS) void pair_bwd_photo_k
 //   dL/d ref_depth: atomic scatter of dL/dD_p over the taps; dL/d tgt_depth: dense accumulate;
 //   dL/d(A|c): block reduction, fp64 atomics per batch element.
 // ==========================================================================================
+#ifndef SCSFM_GEOM_BLOCKS  // tuning knob: workgroups per CU the geometry pass is compiled for
+#define SCSFM_GEOM_BLOCKS 4
+#endif
 template <typename T>
-__global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_GEOM_BLOCKS : 1) void pair_bwd_geom_kernel(
     PairBatch<T> pb, int B, int H, int W, unsigned flags, const T* __restrict__ g_photo,
     const T* __restrict__ g_geom) {
   // natural block order here: with the XCD-contiguous order of the tiled kernels this pass measured 2 %
@@ -465,10 +473,10 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
   // dense dL/d tgt_depth goes to plane 4 of this pair's gbuf (a plain store); pairs_combine_kernel adds
   // it to the caller's buffer afterwards.  That keeps every pair-direction of a step in one launch:
   // the same depth map is the dense target of one pair and the scatter target of another.
-  T* __restrict__ g_tgt_depth = pa.gbuf + 4 * (size_t)B * H * W;
+  T* __restrict__ g_tgt_depth = pa.gbuf + kPlaneDense * (size_t)B * H * W;
   T* __restrict__ g_ref_depth = pa.g_ref_depth;
   double* __restrict__ gP = pa.gPp;
-  constexpr int ROWS = 4;  // pixels per thread: a block covers a 64 x 16 tile
+  constexpr int ROWS = kGeomRows;  // pixels per thread: a block covers a 64 x (4 ROWS) tile
   __shared__ double red[12 * (kThreads / kWave)];
   __shared__ T win[kWinH][kWinW];  // staging window of the scatter into dL/d ref_depth
   if (T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0)) return;  // as in pass A
@@ -510,7 +518,8 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
     const unsigned p = (unsigned(py < H ? py : H - 1) * unsigned(W) + unsigned(px < W ? px : W - 1)) * unsigned(sizeof(T));
     in_d[r] = ld_at(tgt_depth, p);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) in_g[r][c] = ld_at(gbuf + c * gplane, p);
+    for (int c = 0; c < 3; ++c) in_g[r][c] = ld_at(gbuf + (kPlaneGI + c) * gplane, p);
+    in_g[r][3] = ld_at(gbuf + kPlaneGdd * gplane, p);
   }
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
@@ -518,21 +527,19 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
     if (px >= W || py >= H) continue;
     const unsigned p = unsigned(py) * unsigned(W) + unsigned(px);
     const T d = in_d[r];
-    const T gI0 = gscale * in_g[r][0], gI1 = gscale * in_g[r][1], gI2 = gscale * in_g[r][2], g_dd = gscale * in_g[r][3];
+    const T g_dd = gscale * in_g[r][3];
     const Sample<T> s = project_pixel(bc, px, py, d, H, W, flags);
-    const SampleGrad<T> sg = sample_grad(s);
-    T t[4];
-    T gix = T(0), giy = T(0);
-    if (!(flags & SCSFM_DEBUG_X4)) {
-      load_taps(ref_img, s, t);
-      gix = gI0 * dot4(t, sg.cx); giy = gI0 * dot4(t, sg.cy);
-      load_taps(ref_img + plane, s, t);
-      gix += gI1 * dot4(t, sg.cx); giy += gI1 * dot4(t, sg.cy);
-      load_taps(ref_img + 2 * plane, s, t);
-      gix += gI2 * dot4(t, sg.cx); giy += gI2 * dot4(t, sg.cy);
+    T gix = T(0), giy = T(0), dx, dy;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      tap_rows_grad(load_tap_rows(ref_img + c * plane, s), s, dx, dy);
+      const T gI = gscale * in_g[r][c];
+      gix += gI * dx; giy += gI * dy;
     }
-    load_taps(ref_depth, s, t);
-    const T Dp = bilerp(t, s);
+    const TapRows<T> td = load_tap_rows(ref_depth, s);
+    const T Dp = bilerp_rows(td, s);
+    T dDx, dDy;
+    tap_rows_grad(td, s, dDx, dDy);
     const T diff = s.Z - Dp, sum = s.Z + Dp;
     const T isum = t_rcp(sum);
     const T raw = t_abs(diff) * isum;
@@ -542,8 +549,8 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_geom_kernel(
       gZ = g_dd * (sgn * T(2) * Dp * i2);
       gDp = -g_dd * (sgn * T(2) * s.Z * i2);
     }
-    gix += gDp * dot4(t, sg.cx);
-    giy += gDp * dot4(t, sg.cy);
+    gix += gDp * dDx;
+    giy += gDp * dDy;
     if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window(win, wx0, wy0, g_ref_depth, s, gDp);
     const T gd = pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
     st_at(g_tgt_depth, p * unsigned(sizeof(T)), (flags & SCSFM_DEBUG_X2) ? T(0) : gd);
@@ -701,7 +708,7 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
         hipLaunchKernelGGL((pair_bwd_photo_kernel<T, false, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W,
                            flags, g_photo, g_geom, T(0));
     }
-    dim3 grid_b(ceil_div(W, kWave), ceil_div(H, 4 * (kThreads / kWave)), m * B);
+    dim3 grid_b(ceil_div(W, kWave), ceil_div(H, kGeomRows * (kThreads / kWave)), m * B);
     if (!(flags & SCSFM_DEBUG_SKIP_GEOM))
       hipLaunchKernelGGL((pair_bwd_geom_kernel<T>), grid_b, dim3(kThreads), 0, stream, pb, B, H, W, flags, g_photo,
                          g_geom);
@@ -716,7 +723,7 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
         int k = 0;
         while (k < nd && cb.dst[k] != dst) ++k;
         if (k == nd) { cb.dst[nd] = dst; cb.nsrc[nd] = 0; ++nd; }
-        cb.src[k][cb.nsrc[k]] = pb.p[i].gbuf + 4 * npx;
+        cb.src[k][cb.nsrc[k]] = pb.p[i].gbuf + kPlaneDense * npx;
         cb.sums[k][cb.nsrc[k]] = pb.p[i].sums;
         ++cb.nsrc[k];
       }

@@ -51,7 +51,8 @@ struct Px {  // depth and colours of one pixel
 template <typename T>
 __device__ __forceinline__ Px<T> load_px(const T* __restrict__ depth, const T* __restrict__ img, unsigned plane, unsigned p) {
   Px<T> r;
-  r.d = depth[p]; r.c0 = img[p]; r.c1 = img[plane + p]; r.c2 = img[2 * plane + p];
+  const unsigned off = p * unsigned(sizeof(T));
+  r.d = ld_at(depth, off); r.c0 = ld_at(img, off); r.c1 = ld_at(img + plane, off); r.c2 = ld_at(img + 2 * plane, off);
   return r;
 }
 template <typename T>
@@ -63,7 +64,7 @@ __device__ __forceinline__ Px<T> shfl_down_px(const Px<T>& v) {
 // exp(-mean_c |I(p) - I(q)|), loss_functions.py:148-152
 template <typename T>
 __device__ __forceinline__ T edge_weight(const Px<T>& a, const Px<T>& b) {
-  return t_exp(-(t_abs(a.c0 - b.c0) + t_abs(a.c1 - b.c1) + t_abs(a.c2 - b.c2)) / T(3));
+  return t_exp_weight((t_abs(a.c0 - b.c0) + t_abs(a.c1 - b.c1) + t_abs(a.c2 - b.c2)) * T(-1.0 / 3.0));
 }
 
 template <typename T>
@@ -82,19 +83,33 @@ __global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(SmoothBatch<T> sb,
   const int xc = in_x ? x : W - 1;
   const T icx = T(1.0 / ((double)B * H * (W - 1))), icy = T(1.0 / ((double)B * (H - 1) * W));
   T sd = T(0), sx = T(0), sy = T(0);
-  Px<T> cur = load_px(depth, img, plane, unsigned(y0 < H ? y0 : H - 1) * unsigned(W) + unsigned(xc));
-  T ty_prev = T(0);  // lower edge of the row above the strip (only needed for the stored gradient terms)
-  if (edge && y0 > 0 && y0 < H) {
-    const Px<T> up = load_px(depth, img, plane, unsigned(y0 - 1) * unsigned(W) + unsigned(xc));
-    ty_prev = t_sgn(up.d - cur.d) * edge_weight(up, cur) * icy;
+  // every load of the strip first (the rows, each row's right neighbour, and -- for the stored gradient terms --
+  // the row above and lane 0's left neighbours): one memory round trip, no load behind a divergent branch later
+  Px<T> row[kSmRows + 1], rgt[kSmRows], lft[kSmRows], up = {T(0), T(0), T(0), T(0)};
+  const int xr = x + 1 < W ? x + 1 : W - 1;
+#pragma unroll
+  for (int r = 0; r <= kSmRows; ++r)
+    row[r] = load_px(depth, img, plane, unsigned(y0 + r < H ? y0 + r : H - 1) * unsigned(W) + unsigned(xc));
+#pragma unroll
+  for (int r = 0; r < kSmRows; ++r) {
+    rgt[r] = load_px(depth, img, plane, unsigned(y0 + r < H ? y0 + r : H - 1) * unsigned(W) + unsigned(xr));
+    lft[r] = rgt[r];  // (defined for every lane; only lane 0 replaces and uses it)
   }
+  if (edge) {  // workgroup-uniform
+    if (y0 > 0 && y0 < H) up = load_px(depth, img, plane, unsigned(y0 - 1) * unsigned(W) + unsigned(xc));
+    if (lane == 0 && x > 0 && in_x) {
+#pragma unroll
+      for (int r = 0; r < kSmRows; ++r)
+        lft[r] = load_px(depth, img, plane, unsigned(y0 + r < H ? y0 + r : H - 1) * unsigned(W) + unsigned(x - 1));
+    }
+  }
+  T ty_prev = T(0);  // lower edge of the row above the strip (only needed for the stored gradient terms)
+  if (edge && y0 > 0 && y0 < H) ty_prev = t_sgn(up.d - row[0].d) * edge_weight(up, row[0]) * icy;
 #pragma unroll
   for (int r = 0; r < kSmRows; ++r) {
     const int y = y0 + r;
     const unsigned p = unsigned(y < H ? y : H - 1) * unsigned(W) + unsigned(xc);
-    Px<T> right = shfl_down_px(cur);  // every lane takes part
-    if (lane == kWave - 1 && x + 1 < W) right = load_px(depth, img, plane, p + 1);
-    const Px<T> down = load_px(depth, img, plane, unsigned(y + 1 < H ? y + 1 : H - 1) * unsigned(W) + unsigned(xc));
+    const Px<T> cur = row[r], right = rgt[r], down = row[r + 1];
     const bool ex = in_x && y < H && x + 1 < W, ey = in_x && y < H && y + 1 < H;
     const T wx = ex ? edge_weight(cur, right) : T(0), wy = ey ? edge_weight(cur, down) : T(0);
     const T dx = cur.d - right.d, dy = cur.d - down.d;
@@ -104,17 +119,11 @@ __global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(SmoothBatch<T> sb,
     if (edge) {  // workgroup-uniform
       const T tx = t_sgn(dx) * wx * icx, ty = t_sgn(dy) * wy * icy;
       T tx_left = __shfl_up(tx, 1);
-      if (lane == 0) {
-        tx_left = T(0);
-        if (x > 0 && in_x && y < H) {
-          const Px<T> left = load_px(depth, img, plane, p - 1);
-          tx_left = t_sgn(left.d - cur.d) * edge_weight(left, cur) * icx;
-        }
-      }
-      if (in_x && y < H) edge[p] = tx - tx_left + ty - ty_prev;
+      if (lane == 0)
+        tx_left = (x > 0 && in_x && y < H) ? t_sgn(lft[r].d - cur.d) * edge_weight(lft[r], cur) * icx : T(0);
+      if (in_x && y < H) st_at(edge, p * unsigned(sizeof(T)), tx - tx_left + ty - ty_prev);
       ty_prev = ty;
     }
-    cur = down;
   }
   T v[3] = {sd, sx, sy};
   block_sum<3>(v, red);
@@ -154,7 +163,8 @@ __global__ __launch_bounds__(kThreads) void smooth_finalize_kernel(SmoothBatch<T
   }
 }
 
-template <typename T>
+// kAccumulate: g_depth += (the single-frame entry point's contract) instead of a plain store.
+template <typename T, bool kAccumulate>
 __global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(SmoothBatch<T> sb, int B, int H, int W,
                                                               const T* __restrict__ g_loss) {
   const int frame = blockIdx.z / B, b = blockIdx.z - frame * B;
@@ -173,15 +183,16 @@ __global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(SmoothBatch<T> sb,
   const T iden = T(1.0 / fr.per_img[2 * b]);
   const T icx = T(1.0 / ((double)B * H * (W - 1))), icy = T(1.0 / ((double)B * (H - 1) * W));
   const T mean_term = T(fr.per_img[2 * b + 1] / (fr.per_img[2 * b] * fr.per_img[2 * b] * (double)H * W));
-  if (fr.edge) {  // the forward left the per-pixel edge terms: 4 B read + 8 B read-modify-write per pixel
+  if (fr.edge) {  // the forward left the per-pixel edge terms: 4 B read + 4 B written per pixel
     const T* __restrict__ edge = fr.edge + (size_t)b * plane;
     if (in_x) {
 #pragma unroll
       for (int r = 0; r < kSmRows; ++r) {
         const int y = y0 + r;
         if (y >= H) break;
-        const unsigned p = unsigned(y) * unsigned(W) + unsigned(x);
-        g_depth[p] += g * (edge[p] * iden - mean_term);
+        const unsigned off = (unsigned(y) * unsigned(W) + unsigned(x)) * unsigned(sizeof(T));
+        const T v = g * (ld_at(edge, off) * iden - mean_term);
+        st_at(g_depth, off, kAccumulate ? ld_at(g_depth, off) + v : v);
       }
     }
     return;
@@ -211,7 +222,10 @@ __global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(SmoothBatch<T> sb,
         tx_left = t_sgn(left.d - cur.d) * edge_weight(left, cur) * icx;
       }
     }
-    if (in_x && y < H) g_depth[p] += g * ((tx - tx_left + ty - ty_prev) * iden - mean_term);
+    if (in_x && y < H) {
+      const T v = g * ((tx - tx_left + ty - ty_prev) * iden - mean_term);
+      g_depth[p] = kAccumulate ? g_depth[p] + v : v;
+    }
     ty_prev = ty;
     cur = down;
   }
@@ -252,7 +266,7 @@ static int smooth_multi_fwd(int n, const void* const* depths, const void* const*
 
 template <typename T>
 static int smooth_multi_bwd(int n, const void* const* depths, const void* const* imgs, int B, int H, int W, void* ws,
-                            void* const* edges, const T* g_loss, void* const* g_depths, void* stream_) {
+                            void* const* edges, const T* g_loss, void* const* g_depths, bool accumulate, void* stream_) {
   clear_status();
   if (n < 0 || B <= 0 || H < 2 || W < 2 || (n > 0 && (!depths || !imgs || !ws || !g_loss || !g_depths)))
     return SCSFM_ERR_ARG;
@@ -266,8 +280,12 @@ static int smooth_multi_bwd(int n, const void* const* depths, const void* const*
     for (int i = 0; i < m; ++i)
       sb.f[i] = make_frame<T>(B, H, W, depths[i0 + i], imgs[i0 + i], (char*)ws + (size_t)(i0 + i) * l.total, nullptr,
                               g_depths[i0 + i], edges ? edges[i0 + i] : nullptr);
-    hipLaunchKernelGGL((smooth_bwd_kernel<T>), dim3(l.nbx, l.nby, m * B), dim3(kThreads), 0, stream, sb, B, H, W,
-                       g_loss);
+    if (accumulate)
+      hipLaunchKernelGGL((smooth_bwd_kernel<T, true>), dim3(l.nbx, l.nby, m * B), dim3(kThreads), 0, stream, sb, B, H, W,
+                         g_loss);
+    else
+      hipLaunchKernelGGL((smooth_bwd_kernel<T, false>), dim3(l.nbx, l.nby, m * B), dim3(kThreads), 0, stream, sb, B, H, W,
+                         g_loss);
   }
   return launch_status();
 }
@@ -289,7 +307,7 @@ size_t scsfm_smooth_ws_bytes(int B, int H, int W) {
   int scsfm_smooth_multi_bwd_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,   \
                                    void* ws, void* const* edges, const T* g_loss, void* const* g_depths,             \
                                    void* stream) {                                                                   \
-    return scsfm::smooth_multi_bwd<T>(n, depths, imgs, B, H, W, ws, edges, g_loss, g_depths, stream);                \
+    return scsfm::smooth_multi_bwd<T>(n, depths, imgs, B, H, W, ws, edges, g_loss, g_depths, false, stream);         \
   }                                                                                                                  \
   int scsfm_smooth_fwd_##SUF(int B, int H, int W, const T* depth, const T* img, void* ws, T* out, void* stream) {    \
     const void* d = depth; const void* im = img;                                                                     \
@@ -300,7 +318,7 @@ size_t scsfm_smooth_ws_bytes(int B, int H, int W) {
                              T* g_depth, void* stream) {                                                             \
     const void* d = depth; const void* im = img; void* g = g_depth;                                                  \
     if (!depth || !img || !g_depth) return SCSFM_ERR_ARG;                                                            \
-    return scsfm::smooth_multi_bwd<T>(1, &d, &im, B, H, W, ws, nullptr, g_loss, &g, stream);                         \
+    return scsfm::smooth_multi_bwd<T>(1, &d, &im, B, H, W, ws, nullptr, g_loss, &g, true, stream);                   \
   }
 
 SCSFM_SMOOTH_API(f32, float)

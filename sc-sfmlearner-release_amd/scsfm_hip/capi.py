@@ -385,7 +385,8 @@ def smooth_multi_bwd(lib, depths, imgs, ws, g_loss, need=None):
     plane_bytes = ((B * H * W * imgs[0].element_size() + 255) // 256) * 256
     has_edges = ws.numel() == n * (ws_bytes + plane_bytes)
     edges = (_ct.c_void_p * n)(*[ws.data_ptr() + n * ws_bytes + i * plane_bytes for i in range(n)]) if has_edges else None
-    g_all = torch.zeros((n,) + tuple(depths[0].shape), dtype=depths[0].dtype, device=depths[0].device)
+    # the library stores every pixel of a wanted gradient: no zero-fill
+    g_all = torch.empty((n,) + tuple(depths[0].shape), dtype=depths[0].dtype, device=depths[0].device)
     grads = [g_all[i] if (need is None or need[i]) else None for i in range(n)]
     lib.call(f"scsfm_smooth_multi_bwd_{_suffix(imgs[0])}", n, _ptr_array(depths), _ptr_array(imgs), B, H, W, _p(ws),
              edges, _p(g_loss), _ptr_array(grads), _stream(imgs[0]))

@@ -216,3 +216,4 @@ static inline float __saturatef(float x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
 static inline int __float2int_rd(float x) { return (int)floorf(x); }
 #define __builtin_amdgcn_readfirstlane(x) (x)
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
