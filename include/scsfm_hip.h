@@ -73,9 +73,10 @@ int scsfm_abi_version(void);
  *                       over the ranks, recompute out[0..1] and the backward coefficients in `ws`
  *                       from the global sums (the masked means are ratios of whole-batch sums).
  * scsfm_pair_bwd      : `scratch` = scsfm_pair_bwd_scratch_bytes(B,H,W) bytes of device memory, contents
- *                       irrelevant before and after the call (it carries dL/d warped colours and
- *                       dL/d diff_depth between the two backward kernels); may be shared by
- *                       consecutive calls on one stream.
+ *                       irrelevant before and after the call (six planes: dL/d warped colours and
+ *                       dL/d diff_depth between the two backward kernels, then this pair's dense
+ *                       dL/d tgt_depth and scattered dL/d ref_depth before they are added to the
+ *                       caller's buffers); may be shared by consecutive calls on one stream.
  *                       g_photo / g_geom are device scalars (upstream gradients of the two losses).
  *                       g_tgt_depth [B,1,H,W] accumulate (dense), g_ref_depth [B,1,H,W] accumulate
  *                       (atomic scatter of the bilinear taps), g_pose [B,6] store.
@@ -84,11 +85,14 @@ size_t scsfm_pair_ws_bytes(int B, int H, int W);
 size_t scsfm_pair_bwd_scratch_bytes(int B, int H, int W);
 
 /* Speculative forward: same results in `out` / `ws` as scsfm_pair_fwd, but computed by the backward's
- * tiled pass, which also leaves dL/d(warped colours) and dL/d(diff_depth) in `gbuf` up to the factor
- * g_photo / (3 S_mask) -- valid if the upstream gradients of (photo, geom) later stand in the ratio
- * w_photo : w_geom (the loss weights, train.py:268; w_photo != 0).  scsfm_pair_bwd must then be
- * given the same `gbuf` as its `scratch`; it verifies the ratio on the device and silently falls
- * back to recomputing the pass when it does not hold.  One warp + SSIM evaluation less per pair. */
+ * tiled pass followed, in the same kernel, by the geometry pass: `gbuf` receives this pair's dense
+ * dL/d tgt_depth and scattered dL/d ref_depth planes (and `ws` the partials of dL/d pose) up to the
+ * factor g_photo / (3 S_mask), which the reduction only supplies afterwards -- valid if the upstream
+ * gradients of (photo, geom) later stand in the ratio w_photo : w_geom (the loss weights,
+ * train.py:268; w_photo != 0).  scsfm_pair_bwd must then be given the same `gbuf` as its `scratch`;
+ * it verifies the ratio on the device, scales and adds the planes, and silently falls back to
+ * running both passes when the ratio does not hold.  The whole pair-direction is then one kernel in
+ * the forward and a streaming add in the backward. */
 int scsfm_pair_fwd_spec_f32(int B, int H, int W, const float* tgt_img, const float* ref_img,
                             const float* tgt_depth, const float* ref_depth, const float* pose,
                             const float* intrinsics, unsigned flags, void* ws, void* gbuf, double w_photo,
@@ -122,8 +126,11 @@ int scsfm_pair_bwd_f64(int B, int H, int W, const double* tgt_img, const double*
  * needs per step: refs x scales x 2 directions.  `d` is a HOST array of n descriptors holding DEVICE
  * pointers; every pair shares B, H, W, the intrinsics, the flags and (backward) the scratch buffer
  * and the upstream gradients.  Field use: forward reads tgt_img..pose, ws, out; backward reads
- * tgt_img..pose, ws and accumulates / stores g_tgt_depth, g_ref_depth, g_pose.  Semantics per pair
- * are exactly those of scsfm_pair_fwd / scsfm_pair_bwd; the descriptors are consumed before return.
+ * tgt_img..pose, ws and STORES g_tgt_depth, g_ref_depth, g_pose: a depth-gradient buffer named by several
+ * descriptors of one call (the same map is the target of one pair and the reference of another) receives
+ * the sum of their contributions, and needs no zero-fill beforehand (n <= 128 per call).  Otherwise the
+ * semantics per pair are those of scsfm_pair_fwd / scsfm_pair_bwd; the descriptors are consumed before
+ * return.
  * --------------------------------------------------------------------------------------------- */
 typedef struct scsfm_pair_desc {
   const void* tgt_img;

@@ -43,7 +43,8 @@ struct BatchConsts {
 //   [off_sums]         sums     : double[16] = {S_photo, S_geom, S_m, photo, geom, a, b, -, spec, w_photo, w_geom, ...}
 //                                 a = d photo / d sum, b = d geom / d sum (0 when gated off); spec = 1 if the
 //                                 forward was speculative for upstream weights (w_photo, w_geom)
-//   [off_gP]           gPp      : double[B][geom blocks per image][12]  (per-block partial gradients of A|c;
+//   [off_gP]           gPp      : double[B][blocks per image][12]  (per-block partial gradients of A|c, written by
+//                                 the speculative forward's geometry tail or by the geometry pass;
 //                                 reduced by pose_reduce_bwd_kernel -- same-address atomics from ~200 blocks per
 //                                 image cost 60 us per launch, partials cost nothing)
 //   [off_partials]     partials : double[nblocks][3]
@@ -66,7 +67,8 @@ inline PairWs pair_ws_layout(int B, int H, int W) {
   l.nby = ceil_div(H, kTileH);
   size_t off = (size_t)B * sizeof(BatchConsts<double>);
   l.off_sums = off; off += 16 * sizeof(double);
-  l.off_gP = off; off += (size_t)B * ceil_div(W, kWave) * ceil_div(H, 16) * 12 * sizeof(double);
+  // (sized like the partials: the finest tiling that writes them is the fp64 speculative forward's)
+  l.off_gP = off; off += (size_t)B * ceil_div(W, kTileW - 2) * ceil_div(H, 6) * 12 * sizeof(double);
   // partials: sized for the finest tiling that writes them (62 x 6 outputs per block: the fp64 speculative forward)
   l.off_partials = off; off += (size_t)ceil_div(W, kTileW - 2) * ceil_div(H, 6) * B * 3 * sizeof(double);
   l.total = (off + 255) & ~(size_t)255;
@@ -148,9 +150,9 @@ __device__ __forceinline__ void block_sum(T (&v)[N], double* scratch) {
 // This bijection gives XCD k the k-th contiguous eighth of the logical (x fastest, then y, then z) order,
 // i.e. whole images per XCD.
 struct BlockId { int x, y, z; };
-__device__ __forceinline__ BlockId xcd_block_id() {
-  const int nx = gridDim.x, ny = gridDim.y, n = nx * ny * (int)gridDim.z;
-  const int p = ((int)blockIdx.z * ny + (int)blockIdx.y) * nx + (int)blockIdx.x;
+// p = linear id of a workgroup that the dispatcher placed on XCD p % 8 -> the logical tile it should process
+__device__ __forceinline__ BlockId xcd_tile_of(int p, int nx, int ny, int nz) {
+  const int n = nx * ny * nz;
   const int xcd = p & 7, slot = p >> 3, q = n >> 3, r = n & 7;
   const int l = xcd * q + (xcd < r ? xcd : r) + slot;
   BlockId b;
@@ -159,6 +161,10 @@ __device__ __forceinline__ BlockId xcd_block_id() {
   b.y = t % ny;
   b.z = t / ny;
   return b;
+}
+__device__ __forceinline__ BlockId xcd_block_id() {
+  const int nx = gridDim.x, ny = gridDim.y;
+  return xcd_tile_of(((int)blockIdx.z * ny + (int)blockIdx.y) * nx + (int)blockIdx.x, nx, ny, (int)gridDim.z);
 }
 
 __device__ __forceinline__ int reflect_index(int i, int n) {

@@ -136,10 +136,10 @@ __global__ void pose_bwd_kernel(int B, const T* __restrict__ pose, const T* __re
 // written by pair_bwd_geom_kernel, then the pose chain.  `live` = the geometry pass ran (it skips
 // when both upstream coefficients are zero and then leaves the partials untouched).
 template <typename T>
-__device__ __forceinline__ void pose_reduce_one(int b, int nblk, const T* __restrict__ pose, const T* __restrict__ K,
-                                                const double* __restrict__ gPp, const double* __restrict__ sums,
-                                                const T* __restrict__ g_photo, const T* __restrict__ g_geom,
-                                                T* __restrict__ gpose) {
+__device__ __forceinline__ void pose_reduce_one(int b, int nblk, double scale, const T* __restrict__ pose,
+                                                const T* __restrict__ K, const double* __restrict__ gPp,
+                                                const double* __restrict__ sums, const T* __restrict__ g_photo,
+                                                const T* __restrict__ g_geom, T* __restrict__ gpose) {
   const int lane = threadIdx.x;
   const bool live = !(T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0));
   double g[12];
@@ -152,7 +152,7 @@ __device__ __forceinline__ void pose_reduce_one(int b, int nblk, const T* __rest
       for (int i = 0; i < 12; ++i) g[i] += q[i];
     }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) g[i] = wave_sum(g[i]);
+    for (int i = 0; i < 12; ++i) g[i] = wave_sum(g[i]) * scale;
   }
   if (lane == 0) pose_from_gP(K + 9 * b, pose + 6 * b, g, gpose + 6 * b);
 }
@@ -360,43 +360,87 @@ __device__ __forceinline__ void scatter_taps(T* __restrict__ gplane, const Sampl
 #define SCSFM_WIN_W 96
 #define SCSFM_WIN_H 32
 #endif
-constexpr int kWinW = SCSFM_WIN_W, kWinH = SCSFM_WIN_H;
+constexpr int kWinW = SCSFM_WIN_W, kWinH = SCSFM_WIN_H;  // window of a 64 x 16 tile; WH scales with the tile height
 #ifndef SCSFM_GEOM_ROWS
 #define SCSFM_GEOM_ROWS 4
 #endif
 constexpr int kGeomRows = SCSFM_GEOM_ROWS;  // rows per thread of the geometry pass (its tile is 64 x 4 kGeomRows)
 
-template <typename T>
-__device__ __forceinline__ void scatter_taps_window(T (*win)[kWinW], int wx0, int wy0, T* __restrict__ gplane,
+template <typename T, int WW, int WH>
+__device__ __forceinline__ void scatter_taps_window(T (*win)[WW], int wx0, int wy0, T* __restrict__ gplane,
                                                     const Sample<T>& s, T g) {
   if (g == T(0)) return;
   const int lx = s.x0 - wx0, ly = s.y0 - wy0;
-  if (lx >= 0 && lx < kWinW - 1 && ly >= 0 && ly < kWinH - 1) {
+  if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < WH - 1) {
     // unpredicated: an out-of-image tap has weight 0, and adding 0 leaves its cell at the 0 the flush skips
-#if defined(SCSFM_EXPERIMENT_PLAIN_LDS)
-    win[ly][lx] = g * s.w[0]; win[ly][lx + 1] = g * s.w[1]; win[ly + 1][lx] = g * s.w[2]; win[ly + 1][lx + 1] = g * s.w[3];
-#else
     atomicAdd(&win[ly][lx], g * s.w[0]);
     atomicAdd(&win[ly][lx + 1], g * s.w[1]);
     atomicAdd(&win[ly + 1][lx], g * s.w[2]);
     atomicAdd(&win[ly + 1][lx + 1], g * s.w[3]);
-#endif
   } else {
-#if !defined(SCSFM_EXPERIMENT_NO_FALLBACK)
     scatter_taps(gplane, s, g);
-#endif
   }
 }
 
 // Only cells that received an in-image tap are non-zero, so every flushed cell is a valid pixel.
-template <typename T>
-__device__ __forceinline__ void flush_scatter_window(const T (*win)[kWinW], int wx0, int wy0, T* __restrict__ gplane,
+template <typename T, int WW, int WH>
+__device__ __forceinline__ void flush_scatter_window(const T (*win)[WW], int wx0, int wy0, T* __restrict__ gplane,
                                                      int W) {
-  for (int i = threadIdx.x; i < kWinW * kWinH; i += kThreads) {
-    const int ly = i / kWinW, lx = i - ly * kWinW;
+  for (int i = threadIdx.x; i < WW * WH; i += kThreads) {
+    const int ly = i / WW, lx = i - ly * WW;
     const T v = win[ly][lx];
     if (v != T(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), v);
   }
+}
+
+// Where the window of a tile sits: centred on where the tile's centre pixel (ax, ay) lands in the reference
+// view.  Every thread evaluates it (one broadcast load + one projection): handing it over from a single
+// thread would put that thread's dependent load in front of a barrier for the whole block.
+template <typename T, int WW, int WH>
+__device__ __forceinline__ void window_origin(const BatchConsts<T>& bc, int ax, int ay, const T* __restrict__ tgt_depth,
+                                              int H, int W, unsigned flags, int& wx0, int& wy0) {
+  ax = t_clampi(ax, 0, W - 1); ay = t_clampi(ay, 0, H - 1);
+  const Sample<T> sc = project_pixel(bc, ax, ay, tgt_depth[unsigned(ay) * unsigned(W) + unsigned(ax)], H, W, flags);
+  wx0 = sc.x0 - WW / 2;
+  wy0 = sc.y0 - WH / 2;
+}
+
+// Backward of one target pixel through the bilinear sampler and the camera geometry (the per-pixel body of
+// the geometry pass): gathers the taps of the three colours and of the reference depth, folds
+//   dL/d(ix, iy) = sum_c gI_c * dI_w,c/d(ix, iy) + dL/dD_p * dD_p/d(ix, iy),
+// scatters dL/dD_p over the reference-depth taps (LDS window), accumulates dL/d(A|c) into acc[12] and
+// returns dL/d tgt_depth(p).  g_dd = dL/d diff_depth(p).
+// (Measured alternatives, both slower: a software pipeline that requests pixel r + 1's taps before pixel r is
+// consumed, and finishing the whole strip's arithmetic before a separate scatter loop over compact records.)
+template <typename T, int WW, int WH>
+__device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py, T d, const T (&gI)[3], T g_dd,
+                                        const T* __restrict__ ref_img, const T* __restrict__ ref_depth,
+                                        unsigned plane, int H, int W, unsigned flags, T (*win)[WW], int wx0, int wy0,
+                                        T* __restrict__ scatter_plane, T* acc) {
+  const Sample<T> s = project_pixel(bc, px, py, d, H, W, flags);
+  T gix = T(0), giy = T(0), dx, dy;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    tap_rows_grad(load_tap_rows(ref_img + c * plane, s), s, dx, dy);
+    gix += gI[c] * dx; giy += gI[c] * dy;
+  }
+  const TapRows<T> td = load_tap_rows(ref_depth, s);
+  const T Dp = bilerp_rows(td, s);
+  T dDx, dDy;
+  tap_rows_grad(td, s, dDx, dDy);
+  const T diff = s.Z - Dp, sum = s.Z + Dp;
+  const T isum = t_rcp(sum);
+  const T raw = t_abs(diff) * isum;
+  T gZ = T(0), gDp = T(0);
+  if (raw >= T(0) && raw <= T(1)) {  // diff_depth = clamp(|Z - Dp| / (Z + Dp), 0, 1), loss_functions.py:101
+    const T sgn = t_sgn(diff), i2 = isum * isum;
+    gZ = g_dd * (sgn * T(2) * Dp * i2);
+    gDp = -g_dd * (sgn * T(2) * s.Z * i2);
+  }
+  gix += gDp * dDx;
+  giy += gDp * dDy;
+  if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp);
+  return pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
 }
 
 }  // namespace scsfm

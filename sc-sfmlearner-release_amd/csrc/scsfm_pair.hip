@@ -36,7 +36,11 @@ constexpr int kMaxPairs = 8;
 // pass's private dense output.
 constexpr int kPlaneGI = 0;     // planes 0..2: dL/d(warped colour c)
 constexpr int kPlaneGdd = 3;    // dL/d diff_depth
-constexpr int kPlaneDense = 4;  // dL/d tgt_depth of this pair-direction
+constexpr int kPlaneDense = 4;    // dL/d tgt_depth of this pair-direction (dense)
+constexpr int kPlaneScatter = 5;  // dL/d ref_depth of this pair-direction (scattered; zeroed before the scatter)
+constexpr int kNumPlanes = 6;
+// Workgroups of the backward's two passes (persistent: they walk the tiles).  A multiple of the 8 XCDs; 4 per CU.
+constexpr int kPersistentGrid = 1024;
 template <typename T>
 struct PairBatch {
   PairArgs<T> p[kMaxPairs];
@@ -275,14 +279,32 @@ __device__ __forceinline__ bool spec_valid(const double* __restrict__ sums, cons
   return double(g_geom[0]) * gate_g * sums[9] == double(g_photo[0]) * sums[10];  // products of floats: exact
 }
 
+// Bit p: the backward has to run its two passes for pair p (its upstream coefficients are not both zero and the
+// speculative forward did not already do the work).  Evaluated once per workgroup, all pairs' loads in flight
+// together; a launch in which no pair needs anything ends here.
+template <typename T>
+__device__ __forceinline__ unsigned pairs_to_run(const PairBatch<T>& pb, int npairs, const T* __restrict__ g_photo,
+                                                 const T* __restrict__ g_geom) {
+  unsigned live = 0;
+#pragma unroll
+  for (int p = 0; p < kMaxPairs; ++p) {
+    if (p < npairs) {
+      const double* __restrict__ s = pb.p[p].sums;
+      const bool zero = T(s[5]) * g_photo[0] == T(0) && T(s[6]) * g_geom[0] == T(0);
+      if (!zero && !spec_valid(s, g_photo, g_geom)) live |= 1u << p;
+    }
+  }
+  return live;
+}
+
 #ifndef SCSFM_PHOTO_BLOCKS  // tuning knob (tools/build_variants.sh): workgroups per CU the tiled pass is compiled for
 #define SCSFM_PHOTO_BLOCKS 3
 #endif
+// One tile (blk = logical tile of an nbx x nby x (pairs * B) tiling).
 template <typename T, bool kSsim, bool kSpec>
-__global__ __launch_bounds__(kThreads, SCSFM_PHOTO_BLOCKS) void pair_bwd_photo_kernel(
-    PairBatch<T> pb, int B, int H, int W, unsigned flags, const T* __restrict__ g_photo,
-    const T* __restrict__ g_geom, T r_hint) {
-  const BlockId blk = xcd_block_id();
+__device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, const PairBatch<T>& pb, int B, int H,
+                                           int W, unsigned flags, const T* __restrict__ g_photo,
+                                           const T* __restrict__ g_geom, T r_hint) {
   const int pair = blk.z / B, b = blk.z - pair * B;
   const PairArgs<T>& pa = pb.p[pair];
   const T* __restrict__ tgt_img = pa.tgt_img;
@@ -297,7 +319,13 @@ __global__ __launch_bounds__(kThreads, SCSFM_PHOTO_BLOCKS) void pair_bwd_photo_k
   constexpr int TH = Tile<T>::kH, STRIP = TH / (kThreads / kWave);
   __shared__ V2 sXY[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];
   __shared__ T sG[kSsim ? 3 : 1][kSsim ? TH : 1][kSsim ? kTileW : 1];  // 1/9 (g_mu_y, g_E[y^2], g_E[xy]), one colour
-  __shared__ double red[kSpec ? 3 * (kThreads / kWave) : 1];
+  __shared__ double red[kSpec ? 12 * (kThreads / kWave) : 1];
+  // kSpec: staging window of the geometry tail's scatter (its height follows the tile's)
+  constexpr int WW = kWinW, WH = kWinH * TH / kTileH;
+  __shared__ T win[kSpec ? WH : 1][kSpec ? WW : 1];
+  if constexpr (kSpec) {  // zeroed long before its first use (several barriers lie in between)
+    for (int i = threadIdx.x; i < WW * WH; i += kThreads) (&win[0][0])[i] = T(0);
+  }
 
   // upstream gradient x d(masked mean)/d(sum): zero when the 10000-pixel gate was closed
   T a = T(1), bg = r_hint;
@@ -328,6 +356,11 @@ __global__ __launch_bounds__(kThreads, SCSFM_PHOTO_BLOCKS) void pair_bwd_photo_k
   T bsum[STRIP];  // sum_c blend_c of the owned pixel
   T acc_g = T(0), acc_m = T(0);  // kSpec: forward sums over the pixels this block owns
   V2 cen[kSsim ? 1 : STRIP][kSsim ? 1 : 3];
+  // kSpec: dL/d(warped colour c) of the owned pixels waits for the geometry tail -- parked in the LDS tile of
+  // colour c, which is dead by the time that gradient exists (every thread only touches its own slots); in
+  // registers without SSIM
+  static_assert(!kSsim || sizeof(V2) * (TH + 2) * kHaloW >= sizeof(T) * TH * kTileW, "parking space");
+  T gI_reg[(kSpec && !kSsim) ? STRIP : 1][3];
   // ---- phase 0: every streaming load of the strip and of this thread's ring pixel ---------------
   const int u = reflect_index(px, W);
   T in_d[STRIP], in_t[STRIP][3], in_r[STRIP][3], rin_d = T(0), rin_t[3] = {T(0), T(0), T(0)}, rin_r[3];
@@ -418,19 +451,32 @@ __global__ __launch_bounds__(kThreads, SCSFM_PHOTO_BLOCKS) void pair_bwd_photo_k
     for (int k = 0; k < STRIP; ++k) {
       const int ly = strip * STRIP + k, py = py0 + k;
       // note: m(p) = 0 still receives SSIM gradient through its neighbours' windows
-      if (in_x && ly >= 1 && ly <= TH - 2 && py < H)
-        st_at(gbuf + (kPlaneGI + c) * gplane, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gI[k]);
+      if constexpr (kSpec) {
+        if constexpr (kSsim) reinterpret_cast<T*>(&sXY[c][0][0])[ly * kTileW + col] = gI[k]; else gI_reg[k][c] = gI[k];
+      } else {
+        if (in_x && ly >= 1 && ly <= TH - 2 && py < H)
+          st_at(gbuf + (kPlaneGI + c) * gplane, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gI[k]);
+      }
     }
   }
   // dL/d diff_depth: directly (geometry loss) and through the weight mask (no detach, loss_functions.py:111-113)
+  T gdd[STRIP];
 #pragma unroll
-  for (int k = 0; k < STRIP; ++k) {
-    const int ly = strip * STRIP + k, py = py0 + k;
-    if (in_x && ly >= 1 && ly <= TH - 2 && py < H)
-      st_at(gbuf + kPlaneGdd * gplane, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)),
-            bg * mq[k] - (with_mask ? a * mq[k] * bsum[k] : T(0)));
-  }
-  if constexpr (kSpec) {  // the forward's three sums over the pixels this block owns
+  for (int k = 0; k < STRIP; ++k) gdd[k] = bg * mq[k] - (with_mask ? a * mq[k] * bsum[k] : T(0));
+  if constexpr (!kSpec) {
+    // hand over to pass B; this tile's part of the pair's scatter plane is cleared on the way (pass B only
+    // runs when this pass did)
+#pragma unroll
+    for (int k = 0; k < STRIP; ++k) {
+      const int ly = strip * STRIP + k, py = py0 + k;
+      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) {
+        const unsigned off = (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T));
+        st_at(gbuf + kPlaneGdd * gplane, off, gdd[k]);
+        st_at(gbuf + kPlaneScatter * gplane, off, T(0));
+      }
+    }
+  } else {
+    // ---- the forward's three sums over the pixels this block owns ---------------------------------
     T v[3] = {T(0), acc_g, acc_m};
 #pragma unroll
     for (int k = 0; k < STRIP; ++k) {
@@ -438,11 +484,68 @@ __global__ __launch_bounds__(kThreads, SCSFM_PHOTO_BLOCKS) void pair_bwd_photo_k
       // with a = 1, coef = m * (1 - dd) (or m): exactly the weight of blend in the photo sum
       if (in_x && ly >= 1 && ly <= TH - 2 && py < H) v[0] += bsum[k] * coef[k];
     }
-    block_sum<3>(v, red);
+    block_sum<3>(v, red);  // (contains a barrier: the window's zeroes are visible below even without SSIM)
     if (threadIdx.x == 0) {
-      double* o = partials + 3 * ((size_t)(b * gridDim.y + blk.y) * gridDim.x + blk.x);
+      double* o = partials + 3 * ((size_t)(b * nby + blk.y) * nbx + blk.x);
       o[0] = double(v[0]); o[1] = double(v[1]); o[2] = double(v[2]);
     }
+    // ---- geometry tail: pass B for the owned pixels, up to the factor the reduction will supply ----
+    // (everything downstream of dL/d(warped colour), dL/d diff_depth is linear in them: the dense plane, the
+    // scatter plane and the pose partials are all scaled by a = g_photo / (3 S_m) when they are combined)
+    T* __restrict__ g_dense = pa.gbuf + kPlaneDense * gplane + (size_t)b * plane;
+    T* __restrict__ g_scatter = pa.gbuf + kPlaneScatter * gplane + (size_t)b * plane;
+    int wx0, wy0;
+    window_origin<T, WW, WH>(bc, ox + kTileW / 2, oy + TH / 2, tgt_depth, H, W, flags, wx0, wy0);
+    T acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = T(0);
+#pragma unroll
+    for (int k = 0; k < STRIP; ++k) {
+      const int ly = strip * STRIP + k, py = py0 + k;
+      if (!(in_x && ly >= 1 && ly <= TH - 2 && py < H)) continue;
+      T gI[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if constexpr (kSsim) gI[c] = reinterpret_cast<const T*>(&sXY[c][0][0])[ly * kTileW + col]; else gI[c] = gI_reg[k][c];
+      }
+      const T gd = geom_pixel<T, WW, WH>(bc, px, py, in_d[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win,
+                                         wx0, wy0, g_scatter, acc);
+      st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gd);
+    }
+    __syncthreads();
+    flush_scatter_window<T, WW, WH>(win, wx0, wy0, g_scatter, W);
+    __syncthreads();  // `red` is reused
+    block_sum<12>(acc, red);
+    if (threadIdx.x == 0) {
+      double* o = pa.gPp + 12 * ((size_t)(b * nby + blk.y) * nbx + blk.x);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) o[i] = double(acc[i]);
+    }
+  }
+}
+
+// The speculative forward: one tile per workgroup, XCD-aware order.
+template <typename T, bool kSsim>
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) void pair_fwd_spec_kernel(PairBatch<T> pb, int B, int H, int W,
+                                                                                  unsigned flags, T r_hint) {
+  photo_tile<T, kSsim, true>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, pb, B, H, W, flags, nullptr, nullptr, r_hint);
+}
+
+// Pass A of the backward.  Launched with a small persistent grid that walks the tiles: when the speculative
+// forward's results stand (the usual case) every tile returns at once and the launch costs ~1 us instead of
+// the ~12 us of ten thousand empty workgroups.
+template <typename T, bool kSsim>
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) void pair_bwd_photo_kernel(
+    PairBatch<T> pb, int nbx, int nby, int nz, int B, int H, int W, unsigned flags, const T* __restrict__ g_photo,
+    const T* __restrict__ g_geom) {
+  const unsigned live = pairs_to_run(pb, nz / B, g_photo, g_geom);
+  if (!live) return;
+  const int n = nbx * nby * nz;
+  for (int t = blockIdx.x; t < n; t += gridDim.x) {
+    const BlockId blk = xcd_tile_of(t, nbx, nby, nz);
+    if (!((live >> (blk.z / B)) & 1u)) continue;
+    photo_tile<T, kSsim, false>(blk, nbx, nby, pb, B, H, W, flags, g_photo, g_geom, T(0));
+    __syncthreads();  // the tile's LDS is reused
   }
 }
 
@@ -456,12 +559,8 @@ __global__ __launch_bounds__(kThreads, SCSFM_PHOTO_BLOCKS) void pair_bwd_photo_k
 #define SCSFM_GEOM_BLOCKS 4
 #endif
 template <typename T>
-__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_GEOM_BLOCKS : 1) void pair_bwd_geom_kernel(
-    PairBatch<T> pb, int B, int H, int W, unsigned flags, const T* __restrict__ g_photo,
-    const T* __restrict__ g_geom) {
-  // natural block order here: with the XCD-contiguous order of the tiled kernels this pass measured 2 %
-  // slower (its scatter / flush atomics then hit one image's lines from a single XCD at a time)
-  const BlockId blk = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+__device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, const PairBatch<T>& pb, int B, int H, int W,
+                                          unsigned flags, const T* __restrict__ g_photo, const T* __restrict__ g_geom) {
   const int pair = blk.z / B, b = blk.z - pair * B;
   const PairArgs<T>& pa = pb.p[pair];
   const T* __restrict__ ref_img = pa.ref_img;
@@ -470,18 +569,12 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_GEOM_BLOCKS : 1) v
   const BatchConsts<T>* __restrict__ consts = pa.consts;
   const double* __restrict__ sums = pa.sums;
   const T* __restrict__ gbuf = pa.gbuf;
-  // dense dL/d tgt_depth goes to plane 4 of this pair's gbuf (a plain store); pairs_combine_kernel adds
-  // it to the caller's buffer afterwards.  That keeps every pair-direction of a step in one launch:
-  // the same depth map is the dense target of one pair and the scatter target of another.
-  T* __restrict__ g_tgt_depth = pa.gbuf + kPlaneDense * (size_t)B * H * W;
-  T* __restrict__ g_ref_depth = pa.g_ref_depth;
   double* __restrict__ gP = pa.gPp;
   constexpr int ROWS = kGeomRows;  // pixels per thread: a block covers a 64 x (4 ROWS) tile
   __shared__ double red[12 * (kThreads / kWave)];
   __shared__ T win[kWinH][kWinW];  // staging window of the scatter into dL/d ref_depth
   if (T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0)) return;  // as in pass A
-  // planes left by a speculative forward lack the common factor a = g_photo / (3 S_m)
-  const T gscale = spec_valid(sums, g_photo, g_geom) ? T(sums[5]) * g_photo[0] : T(1);
+  if (spec_valid(sums, g_photo, g_geom)) return;  // the speculative forward already ran this pass in its tail
   const int px = blk.x * kWave + (threadIdx.x & (kWave - 1));
   const int py0 = (blk.y * (kThreads / kWave) + threadIdx.x / kWave) * ROWS;
   const BatchConsts<T> bc = consts[b];
@@ -490,22 +583,17 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_GEOM_BLOCKS : 1) v
   ref_img += (size_t)b * 3 * plane;
   tgt_depth += (size_t)b * plane;
   ref_depth += (size_t)b * plane;
-  g_tgt_depth += (size_t)b * plane;
-  g_ref_depth += (size_t)b * plane;
   gbuf += (size_t)b * plane;
+  // both outputs go to private planes of this pair's gbuf (dense: plain stores; scatter: atomics into the plane
+  // pass A zeroed); pairs_combine_kernel adds them to the callers' buffers.  That keeps every pair-direction of
+  // a step in one launch: the same depth map is the dense target of one pair and the scatter target of another.
+  T* __restrict__ g_dense = pa.gbuf + kPlaneDense * gplane + (size_t)b * plane;
+  T* __restrict__ g_scatter = pa.gbuf + kPlaneScatter * gplane + (size_t)b * plane;
   for (int i = threadIdx.x; i < kWinW * kWinH; i += kThreads) (&win[0][0])[i] = T(0);
   __syncthreads();
-  // window origin: centred on where the tile's centre pixel lands in the reference view.  Every thread
-  // evaluates it (one broadcast load + one projection): handing it over from a single thread would put
-  // that thread's dependent load in front of a barrier for the whole block.
   int wx0, wy0;
-  {
-    const int ax = t_clampi(blk.x * kWave + kWave / 2, 0, W - 1);
-    const int ay = t_clampi(blk.y * (kThreads / kWave) * ROWS + 2 * ROWS, 0, H - 1);
-    const Sample<T> sc = project_pixel(bc, ax, ay, tgt_depth[unsigned(ay) * unsigned(W) + unsigned(ax)], H, W, flags);
-    wx0 = sc.x0 - kWinW / 2;
-    wy0 = sc.y0 - kWinH / 2;
-  }
+  window_origin<T, kWinW, kWinH>(bc, blk.x * kWave + kWave / 2, blk.y * (kThreads / kWave) * ROWS + 2 * ROWS, tgt_depth,
+                                 H, W, flags, wx0, wy0);
   T acc[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) acc[i] = T(0);
@@ -525,84 +613,141 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_GEOM_BLOCKS : 1) v
   for (int r = 0; r < ROWS; ++r) {
     const int py = py0 + r;
     if (px >= W || py >= H) continue;
-    const unsigned p = unsigned(py) * unsigned(W) + unsigned(px);
-    const T d = in_d[r];
-    const T g_dd = gscale * in_g[r][3];
-    const Sample<T> s = project_pixel(bc, px, py, d, H, W, flags);
-    T gix = T(0), giy = T(0), dx, dy;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      tap_rows_grad(load_tap_rows(ref_img + c * plane, s), s, dx, dy);
-      const T gI = gscale * in_g[r][c];
-      gix += gI * dx; giy += gI * dy;
-    }
-    const TapRows<T> td = load_tap_rows(ref_depth, s);
-    const T Dp = bilerp_rows(td, s);
-    T dDx, dDy;
-    tap_rows_grad(td, s, dDx, dDy);
-    const T diff = s.Z - Dp, sum = s.Z + Dp;
-    const T isum = t_rcp(sum);
-    const T raw = t_abs(diff) * isum;
-    T gZ = T(0), gDp = T(0);
-    if (raw >= T(0) && raw <= T(1)) {  // diff_depth = clamp(|Z - Dp| / (Z + Dp), 0, 1), loss_functions.py:101
-      const T sgn = t_sgn(diff), i2 = isum * isum;
-      gZ = g_dd * (sgn * T(2) * Dp * i2);
-      gDp = -g_dd * (sgn * T(2) * s.Z * i2);
-    }
-    gix += gDp * dDx;
-    giy += gDp * dDy;
-    if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window(win, wx0, wy0, g_ref_depth, s, gDp);
-    const T gd = pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
-    st_at(g_tgt_depth, p * unsigned(sizeof(T)), (flags & SCSFM_DEBUG_X2) ? T(0) : gd);
+    const T gI[3] = {in_g[r][0], in_g[r][1], in_g[r][2]};
+    const T gd = geom_pixel<T, kWinW, kWinH>(bc, px, py, in_d[r], gI, in_g[r][3], ref_img, ref_depth, plane, H, W, flags,
+                                             win, wx0, wy0, g_scatter, acc);
+    st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), (flags & SCSFM_DEBUG_X2) ? T(0) : gd);
   }
   __syncthreads();
-  if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5))) flush_scatter_window(win, wx0, wy0, g_ref_depth, W);
+  if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5))) flush_scatter_window<T, kWinW, kWinH>(win, wx0, wy0, g_scatter, W);
   if (flags & SCSFM_DEBUG_X3) {  // profiling: keep the partials defined
     if (threadIdx.x == 0)
-      for (int i = 0; i < 12; ++i) gP[12 * ((size_t)(b * gridDim.y + blk.y) * gridDim.x + blk.x) + i] = 0.0;
+      for (int i = 0; i < 12; ++i) gP[12 * ((size_t)(b * nby + blk.y) * nbx + blk.x) + i] = 0.0;
     return;
   }
   block_sum<12>(acc, red);
   if (threadIdx.x == 0) {
-    double* o = gP + 12 * ((size_t)(b * gridDim.y + blk.y) * gridDim.x + blk.x);
+    double* o = gP + 12 * ((size_t)(b * nby + blk.y) * nbx + blk.x);
 #pragma unroll
     for (int i = 0; i < 12; ++i) o[i] = double(acc[i]);
   }
 }
 
-// One wave per (pair, batch element): reduce the geometry pass's per-block partials, finish dL/dpose.
+// Persistent grid over the tiles, natural order (with the XCD-contiguous order of the tiled kernels this pass
+// measured 2 % slower: its scatter / flush atomics then hit one image's lines from a single XCD at a time).
+// Like pass A it returns at once per tile when the speculative forward's results stand.
 template <typename T>
-__global__ void pairs_pose_reduce_kernel(PairBatch<T> pb, int B, int nblk, const T* __restrict__ K,
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_GEOM_BLOCKS : 1) void pair_bwd_geom_kernel(
+    PairBatch<T> pb, int nbx, int nby, int nz, int B, int H, int W, unsigned flags, const T* __restrict__ g_photo,
+    const T* __restrict__ g_geom) {
+  const unsigned live = pairs_to_run(pb, nz / B, g_photo, g_geom);
+  if (!live) return;
+  const int n = nbx * nby * nz;
+  for (int t = blockIdx.x; t < n; t += gridDim.x) {
+    BlockId blk;
+    blk.x = t % nbx;
+    const int q = t / nbx;
+    blk.y = q % nby;
+    blk.z = q / nby;
+    if (!((live >> (blk.z / B)) & 1u)) continue;
+    geom_tile<T>(blk, nbx, nby, pb, B, H, W, flags, g_photo, g_geom);
+    __syncthreads();  // the window is reused
+  }
+}
+
+// The factor the planes and pose partials of a pair still lack: those of a (valid) speculative forward were
+// computed with unit photo coefficient, those of the backward's own passes are final.
+template <typename T>
+__device__ __forceinline__ T pair_scale(const double* __restrict__ sums, const T* __restrict__ g_photo,
+                                        const T* __restrict__ g_geom) {
+  return spec_valid(sums, g_photo, g_geom) ? T(sums[5]) * g_photo[0] : T(1);
+}
+
+// One wave per (pair, batch element): reduce the per-block partials of dL/d(A|c), finish dL/dpose.
+// nblk_spec / nblk_geom: blocks per image of the kernel that wrote them (geometry tail of the speculative
+// forward, or the geometry pass).
+template <typename T>
+__global__ void pairs_pose_reduce_kernel(PairBatch<T> pb, int B, int nblk_spec, int nblk_geom, const T* __restrict__ K,
                                          const T* __restrict__ g_photo, const T* __restrict__ g_geom) {
   const int pair = blockIdx.x / B, b = blockIdx.x - pair * B;
   const PairArgs<T>& pa = pb.p[pair];
-  pose_reduce_one(b, nblk, pa.pose, K, pa.gPp, pa.sums, g_photo, g_geom, pa.g_pose);
+  const bool spec = spec_valid(pa.sums, g_photo, g_geom);
+  pose_reduce_one(b, spec ? nblk_spec : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K, pa.gPp,
+                  pa.sums, g_photo, g_geom, pa.g_pose);
 }
 
-// dst[d] += sum of the dense planes of the pairs whose target depth map it is.  A pair whose geometry
-// pass skipped (both upstream coefficients zero) left its plane untouched and is skipped here too.
+// dst[d] (+)= sum_k scale_k * src_k: the dense planes of the pairs whose target depth map dst is and the scatter
+// planes of the pairs that sampled it.  A pair whose passes skipped (both upstream coefficients zero) left its
+// planes untouched and is skipped here too.
 template <typename T>
 struct CombineBatch {
-  T* dst[kMaxPairs];
-  int nsrc[kMaxPairs];
-  const T* src[kMaxPairs][kMaxPairs];
-  const double* sums[kMaxPairs][kMaxPairs];
+  T* dst[2 * kMaxPairs];
+  int nsrc[2 * kMaxPairs];
+  int store[2 * kMaxPairs];  // 1: dst = sum (the first time a call touches this buffer), 0: dst += sum
+  const T* src[2 * kMaxPairs][2 * kMaxPairs];
+  const double* sums[2 * kMaxPairs][2 * kMaxPairs];
 };
+
+template <typename T>
+struct alignas(16) Quad { T v[16 / sizeof(T)]; };  // 16-byte vector access
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T> cb, size_t n,
                                                                  const T* __restrict__ g_photo,
                                                                  const T* __restrict__ g_geom) {
+  constexpr int Q = 16 / sizeof(T);
   const int d = blockIdx.y;
   T* __restrict__ dst = cb.dst[d];
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) {
-    T acc = T(0);
-    for (int k = 0; k < cb.nsrc[d]; ++k) {
+  const int ns = cb.nsrc[d];
+  const bool store = cb.store[d] != 0;
+  T scale[2 * kMaxPairs];
+#pragma unroll
+  for (int k = 0; k < 2 * kMaxPairs; ++k) {
+    scale[k] = T(0);
+    if (k < ns) {
       const double* s = cb.sums[d][k];
-      if (!(T(s[5]) * g_photo[0] == T(0) && T(s[6]) * g_geom[0] == T(0))) acc += cb.src[d][k][i];
+      const bool live = !(T(s[5]) * g_photo[0] == T(0) && T(s[6]) * g_geom[0] == T(0));
+      scale[k] = live ? pair_scale(s, g_photo, g_geom) : T(0);
     }
-    dst[i] += acc;
   }
+  // 16-byte accesses over the part every plane has 16-byte aligned (n is a multiple of Q for every image size
+  // in use; the scalar loop below takes whatever is left)
+  bool aligned = (reinterpret_cast<size_t>(dst) & 15) == 0;
+  for (int k = 0; k < ns; ++k) aligned = aligned && (reinterpret_cast<size_t>(cb.src[d][k]) & 15) == 0;
+  const size_t nq = aligned ? n / Q : 0;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nq; i += (size_t)gridDim.x * kThreads) {
+    Quad<T> acc;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) acc.v[j] = T(0);
+#pragma unroll
+    for (int k = 0; k < 2 * kMaxPairs; ++k) {
+      if (k < ns && scale[k] != T(0)) {
+        const Quad<T> x = reinterpret_cast<const Quad<T>*>(cb.src[d][k])[i];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) acc.v[j] += scale[k] * x.v[j];
+      }
+    }
+    if (!store) {
+      const Quad<T> o = reinterpret_cast<const Quad<T>*>(dst)[i];
+#pragma unroll
+      for (int j = 0; j < Q; ++j) acc.v[j] += o.v[j];
+    }
+    reinterpret_cast<Quad<T>*>(dst)[i] = acc;
+  }
+  for (size_t i = nq * Q + (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) {
+    T acc = T(0);
+#pragma unroll
+    for (int k = 0; k < 2 * kMaxPairs; ++k)
+      if (k < ns && scale[k] != T(0)) acc += scale[k] * cb.src[d][k][i];
+    dst[i] = store ? acc : dst[i] + acc;
+  }
+}
+
+// Clears the scatter plane of every pair of a batch (before a speculative forward's geometry tail).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pairs_zero_scatter_kernel(PairBatch<T> pb, size_t n) {
+  T* __restrict__ p = pb.p[blockIdx.y].gbuf + kPlaneScatter * n;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) p[i] = T(0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -643,14 +788,14 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
     hipLaunchKernelGGL((pairs_prep_kernel<T>), dim3(ceil_div(n * B, 64)), dim3(64), 0, stream, pb, n, B, K);
   dim3 grid;
   if (spec) {
+    const size_t npx = (size_t)B * H * W;
+    hipLaunchKernelGGL((pairs_zero_scatter_kernel<T>), dim3(1024, n), dim3(kThreads), 0, stream, pb, npx);
     grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
     const T r_hint = T(3.0 * w_geom / w_photo);
     if (flags & SCSFM_WITH_SSIM)
-      hipLaunchKernelGGL((pair_bwd_photo_kernel<T, true, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags,
-                         (const T*)nullptr, (const T*)nullptr, r_hint);
+      hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags, r_hint);
     else
-      hipLaunchKernelGGL((pair_bwd_photo_kernel<T, false, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags,
-                         (const T*)nullptr, (const T*)nullptr, r_hint);
+      hipLaunchKernelGGL((pair_fwd_spec_kernel<T, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags, r_hint);
   } else {
     grid = dim3(ceil_div(W, kTileW), ceil_div(H, Tile<T>::kH), n * B);
     if (flags & SCSFM_WITH_SSIM)
@@ -687,7 +832,7 @@ static int pairs_fwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
 
 template <typename T>
 static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags, void* scratch,
-                     const T* g_photo, const T* g_geom, void* stream_) {
+                     const T* g_photo, const T* g_geom, bool accumulate, void* stream_) {
   clear_status();
   if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !K || !g_photo || !g_geom) return SCSFM_ERR_ARG;
   for (int i = 0; i < n; ++i)
@@ -695,39 +840,57 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
       return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const size_t npx = (size_t)B * H * W;
+  // store mode: the depth-gradient buffers this call has written so far (later chunks add to them)
+  constexpr int kSeenMax = 256;
+  const void* seen[kSeenMax];
+  int nseen = 0;
+  if (!accumulate && 2 * n > kSeenMax) return SCSFM_ERR_ARG;
   for (int i0 = 0; i0 < n; i0 += kMaxPairs) {
     const int m = n - i0 < kMaxPairs ? n - i0 : kMaxPairs;
     PairBatch<T> pb;
     for (int i = 0; i < m; ++i) pb.p[i] = make_pair_args<T>(d[i0 + i], B, H, W, scratch, i0 + i);
+    const int nax = ceil_div(W, kTileW - 2), nay = ceil_div(H, Tile<T>::kH - 2);
+    const int nbx = ceil_div(W, kWave), nby = ceil_div(H, kGeomRows * (kThreads / kWave));
     if (!(flags & SCSFM_DEBUG_SKIP_PHOTO)) {
-      dim3 grid(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), m * B);
+      const int g = nax * nay * m * B < kPersistentGrid ? nax * nay * m * B : kPersistentGrid;
       if (flags & SCSFM_WITH_SSIM)
-        hipLaunchKernelGGL((pair_bwd_photo_kernel<T, true, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags,
-                           g_photo, g_geom, T(0));
+        hipLaunchKernelGGL((pair_bwd_photo_kernel<T, true>), dim3(g), dim3(kThreads), 0, stream, pb, nax, nay, m * B, B, H, W,
+                           flags, g_photo, g_geom);
       else
-        hipLaunchKernelGGL((pair_bwd_photo_kernel<T, false, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W,
-                           flags, g_photo, g_geom, T(0));
+        hipLaunchKernelGGL((pair_bwd_photo_kernel<T, false>), dim3(g), dim3(kThreads), 0, stream, pb, nax, nay, m * B, B, H,
+                           W, flags, g_photo, g_geom);
     }
-    dim3 grid_b(ceil_div(W, kWave), ceil_div(H, kGeomRows * (kThreads / kWave)), m * B);
-    if (!(flags & SCSFM_DEBUG_SKIP_GEOM))
-      hipLaunchKernelGGL((pair_bwd_geom_kernel<T>), grid_b, dim3(kThreads), 0, stream, pb, B, H, W, flags, g_photo,
-                         g_geom);
-    hipLaunchKernelGGL((pairs_pose_reduce_kernel<T>), dim3(m * B), dim3(kWave), 0, stream, pb, B,
-                       (int)(grid_b.x * grid_b.y), K, g_photo, g_geom);
     if (!(flags & SCSFM_DEBUG_SKIP_GEOM)) {
-      // group the dense planes by the caller's destination buffer
+      const int g = nbx * nby * m * B < kPersistentGrid ? nbx * nby * m * B : kPersistentGrid;
+      hipLaunchKernelGGL((pair_bwd_geom_kernel<T>), dim3(g), dim3(kThreads), 0, stream, pb, nbx, nby, m * B, B, H, W, flags,
+                         g_photo, g_geom);
+    }
+    hipLaunchKernelGGL((pairs_pose_reduce_kernel<T>), dim3(m * B), dim3(kWave), 0, stream, pb, B,
+                       nax * nay, nbx * nby, K, g_photo, g_geom);
+    if (!(flags & SCSFM_DEBUG_SKIP_GEOM)) {
+      // group the private planes by the caller's destination buffer: a pair's dense plane belongs to its
+      // target depth map, its scatter plane to its reference depth map
       CombineBatch<T> cb;
       int nd = 0;
       for (int i = 0; i < m; ++i) {
-        T* dst = (T*)d[i0 + i].g_tgt_depth;
-        int k = 0;
-        while (k < nd && cb.dst[k] != dst) ++k;
-        if (k == nd) { cb.dst[nd] = dst; cb.nsrc[nd] = 0; ++nd; }
-        cb.src[k][cb.nsrc[k]] = pb.p[i].gbuf + kPlaneDense * npx;
-        cb.sums[k][cb.nsrc[k]] = pb.p[i].sums;
-        ++cb.nsrc[k];
+        for (int which = 0; which < 2; ++which) {
+          T* dst = (T*)(which == 0 ? d[i0 + i].g_tgt_depth : d[i0 + i].g_ref_depth);
+          int k = 0;
+          while (k < nd && cb.dst[k] != dst) ++k;
+          if (k == nd) {
+            cb.dst[nd] = dst; cb.nsrc[nd] = 0;
+            int q = 0;
+            while (q < nseen && seen[q] != dst) ++q;
+            cb.store[nd] = (!accumulate && q == nseen && nseen < kSeenMax) ? 1 : 0;
+            if (q == nseen && nseen < kSeenMax) seen[nseen++] = dst;
+            ++nd;
+          }
+          cb.src[k][cb.nsrc[k]] = pb.p[i].gbuf + (which == 0 ? kPlaneDense : kPlaneScatter) * npx;
+          cb.sums[k][cb.nsrc[k]] = pb.p[i].sums;
+          ++cb.nsrc[k];
+        }
       }
-      const int gx = (int)((npx + 4 * kThreads - 1) / (4 * kThreads));
+      const int gx = (int)((npx + 8 * kThreads - 1) / (8 * kThreads));
       hipLaunchKernelGGL((pairs_combine_kernel<T>), dim3(gx < 1 ? 1 : gx, nd), dim3(kThreads), 0, stream, cb, npx,
                          g_photo, g_geom);
     }
@@ -760,8 +923,9 @@ extern "C" {
 
 size_t scsfm_pair_bwd_scratch_bytes(int B, int H, int W) {
   if (B <= 0 || H < 2 || W < 2) return 0;
-  // five planes per pair-direction (dL/dI_w x3, dL/d diff_depth, dense dL/d tgt_depth); sized for fp64
-  return (((size_t)5 * B * H * W * sizeof(double)) + 255) & ~(size_t)255;
+  // six planes per pair-direction (dL/dI_w x3, dL/d diff_depth, dense dL/d tgt_depth, scattered dL/d ref_depth);
+  // sized for fp64
+  return (((size_t)scsfm::kNumPlanes * B * H * W * sizeof(double)) + 255) & ~(size_t)255;
 }
 
 size_t scsfm_pair_ws_bytes(int B, int H, int W) {
@@ -776,7 +940,7 @@ size_t scsfm_pair_ws_bytes(int B, int H, int W) {
   }                                                                                                                   \
   int scsfm_pairs_bwd_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,          \
                             void* scratch, const T* g_photo, const T* g_geom, void* stream) {                         \
-    return scsfm::pairs_bwd<T>(n, d, B, H, W, K, flags, scratch, g_photo, g_geom, stream);                            \
+    return scsfm::pairs_bwd<T>(n, d, B, H, W, K, flags, scratch, g_photo, g_geom, false, stream);                     \
   }                                                                                                                   \
   int scsfm_pair_fwd_##SUF(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth,               \
                            const T* ref_depth, const T* pose, const T* K, unsigned flags, void* ws, T* out,           \
@@ -798,7 +962,7 @@ size_t scsfm_pair_ws_bytes(int B, int H, int W) {
     if (!scratch) return SCSFM_ERR_ARG;                                                                               \
     scsfm_pair_desc d = scsfm::one_desc<T>(tgt_img, ref_img, tgt_depth, ref_depth, pose, ws, 0, g_tgt_depth,           \
                                            g_ref_depth, g_pose, scratch);                                             \
-    return scsfm::pairs_bwd<T>(1, &d, B, H, W, K, flags, scratch, g_photo, g_geom, stream);                           \
+    return scsfm::pairs_bwd<T>(1, &d, B, H, W, K, flags, scratch, g_photo, g_geom, true, stream);                     \
   }                                                                                                                   \
   int scsfm_pair_refinalize_##SUF(int B, int H, int W, void* ws, T* out, void* stream) {                              \
     return scsfm::pair_refinalize<T>(B, H, W, ws, out, stream);                                                       \

@@ -308,18 +308,18 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
 def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws, g_photo,
                        g_geom):
     """Gradients of photo_geometry_fwd's two sums: (g_tgt_depths[s], g_ref_depths[i][s], g_poses[i],
-    g_poses_inv[i]).  Each depth map's gradient buffer is zeroed once and then accumulated into by
-    every pair-direction that touches it (dense writes as target, scatter as reference); one call
-    into the library, pair kernels ordered on the stream, one shared scratch buffer."""
+    g_poses_inv[i]).  Each depth map's gradient buffer receives the sum over every pair-direction that
+    touches it (dense as target, scattered as reference) from the library's combining kernel, which
+    stores (no zero-fill); one call into the library, one shared scratch buffer."""
     B, _, H, W = tgt_img.shape
     pairs = _pair_list(tgt_img, ref_imgs, tgt_depths, ref_depths, poses, poses_inv)
     n = len(pairs)
     ws_bytes, scratch_bytes, _ = _sizes(lib, B, H, W)
     spec = ws.numel() == n * (ws_bytes + scratch_bytes)  # the forward was speculative: gbuf follows each workspace
     stride = ws_bytes + (scratch_bytes if spec else 0)
-    # one zero-fill for every depth-gradient buffer (they all have the full-resolution shape)
+    # one allocation for every depth-gradient buffer (full-resolution shape); the library stores into them
     n_maps = len(tgt_depths) * (1 + len(ref_depths))
-    g_all = torch.zeros((n_maps,) + tuple(tgt_depths[0].shape), dtype=tgt_img.dtype, device=tgt_img.device)
+    g_all = torch.empty((n_maps,) + tuple(tgt_depths[0].shape), dtype=tgt_img.dtype, device=tgt_img.device)
     g_td = [g_all[s] for s in range(len(tgt_depths))]
     g_rd = [[g_all[len(tgt_depths) * (1 + i) + s] for s in range(len(tgt_depths))] for i in range(len(ref_depths))]
     g_pose_all = torch.empty(n, B, 6, dtype=tgt_img.dtype, device=tgt_img.device)
