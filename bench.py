@@ -13,8 +13,9 @@ zeros padding, 1 scale; inputs are resident in HBM before the timed region.  Dat
 shard by batch (weak scaling, 12 samples per GPU) with no collective on the loss path.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (pair_bwd_photo_kernel as speculative forward, all pair-directions in
-                  one launch): algorithmic bytes per launch (48 B/pixel x B*H*W x pair-directions) / its
+  roofline     -- the dominant kernel (pair_fwd_spec_kernel: the speculative forward = warp + losses + both
+                  backward passes of all pair-directions in one launch): algorithmic bytes per launch (SURVEY 8d:
+                  48 B/pixel per pair-direction forward + backward x B*H*W x pair-directions) / its
                   average launch duration measured here with HIP events on the launching stream, against
                   the 8 TB/s HBM3E peak
   cpu_baseline -- the CPU oracle (restatement of the reference's loss path on the same ATen CPU ops)
@@ -81,7 +82,7 @@ def pmc_traffic(args, n_pairs):
         return None
     try:
         d = json.load(open(path))
-        k = d[f"scsfm::pair_bwd_photo_kernel<float, true, true>|gz{n_pairs * args.batch}"]
+        k = d[f"scsfm::pair_fwd_spec_kernel<float, true>|gz{n_pairs * args.batch}"]
         return int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
     except (KeyError, ValueError):
         return None
@@ -103,10 +104,10 @@ def _event_time(fn, iters):
 def time_kernels(x, flags, iters, n_ref):
     """Average duration (HIP events on the launching stream = torch's current stream) of the library
     calls a step is made of, at the step's real launch shapes: the speculative forward of all
-    2*n_ref pair-directions (one pairs_prep + ONE pair_bwd_photo_kernel<.,.,spec> launch + one finalize),
+    2*n_ref pair-directions (pairs_prep + scatter-plane clear + ONE pair_fwd_spec_kernel launch + finalize),
     their backward (geometry pass + pose reduce + combine, one launch each), and the smooth loss of the
     1+n_ref frames.  The figure of a stage contains its few-microsecond helper kernels, i.e. it over-
-    rather than under-states it; `photo_spec_kernel_only` launches the dominant kernel alone (the figure the
+    rather than under-states it; `spec_kernel_only` launches the dominant kernel alone (the figure the
     roofline uses; it agrees with rocprofv3's per-kernel average)."""
     from scsfm_hip import _lib, capi
     lib = _lib.get()
@@ -124,7 +125,7 @@ def time_kernels(x, flags, iters, n_ref):
     calls = {
         "pairs_fwd_spec": lambda: capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, hint=hint),
         # the dominant kernel alone (constants from the call above are still in ws_spec)
-        "photo_spec_kernel_only": lambda: capi.photo_geometry_fwd(lib, fl | 16384, tgt, K, refs, tds, rds, ps, pis,
+        "spec_kernel_only": lambda: capi.photo_geometry_fwd(lib, fl | 16384, tgt, K, refs, tds, rds, ps, pis,
                                                                   hint=hint, ws=ws_spec),
         "pairs_fwd_plain": lambda: capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, hint=None),
         "pairs_bwd_after_spec": lambda: capi.photo_geometry_bwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, ws_spec, one, half),
@@ -296,15 +297,17 @@ def main():
 
     kt = time_kernels(x, flags, args.kernel_iters, args.n_ref)
     n_pairs = 2 * args.n_ref
-    # dominant kernel: pair_bwd_photo_kernel in its speculative-forward form, all pair-directions in one
-    # launch.  Algorithmic bytes per launch: per pair-direction it must read both images and both depth
-    # maps once (32 B/px) and write dL/d(warped colours, diff_depth) once (16 B/px).
+    # dominant kernel: pair_fwd_spec_kernel, all pair-directions in one launch -- per pair-direction the warp,
+    # the masked photometric / geometry sums AND the whole backward up to a scalar factor (tiled SSIM pass +
+    # geometry tail: dense dL/dD_tgt plane, scattered dL/dD_ref plane, pose partials).  Algorithmic bytes per
+    # launch: per pair-direction both images and both depth maps are read once (32 B/px) and the
+    # two depth gradients are written once and read-modify-written once (16 B/px).
     spec_bytes = n_pairs * 48 * n_px
-    achieved = spec_bytes / kt["photo_spec_kernel_only"] / 1e9
-    roofline = {"bound": "hbm", "kernel": f"pair_bwd_photo_kernel<float,true,true> ({n_pairs} pair-directions per launch)",
+    achieved = spec_bytes / kt["spec_kernel_only"] / 1e9
+    roofline = {"bound": "hbm", "kernel": f"pair_fwd_spec_kernel<float,true> ({n_pairs} pair-directions per launch)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, n_pairs),
-                "algorithmic_bytes_per_launch": spec_bytes, "avg_launch_us": round(kt["photo_spec_kernel_only"] * 1e6, 2)}
+                "algorithmic_bytes_per_launch": spec_bytes, "avg_launch_us": round(kt["spec_kernel_only"] * 1e6, 2)}
     # SURVEY.md 8d figure: one pair-direction forward + backward = 48 B/px
     pair_t = (kt["pairs_fwd_spec"] + kt["pairs_bwd_after_spec"]) / n_pairs
     pair_roofline = {"algorithmic_bytes": 48 * n_px, "us": round(pair_t * 1e6, 2),

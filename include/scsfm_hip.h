@@ -42,7 +42,7 @@ extern "C" {
 #define SCSFM_DEBUG_X1 1024u  /* no scatter into g_ref_depth (no LDS window, no atomics) */
 #define SCSFM_DEBUG_X2 2048u  /* no dense accumulate into g_tgt_depth */
 #define SCSFM_DEBUG_X3 4096u  /* no 12-value block reduction / gP atomics */
-#define SCSFM_DEBUG_X4 8192u  /* unused (the colour taps moved into the tiled pass) */
+#define SCSFM_DEBUG_X4 8192u  /* speculative forward: skip the per-pixel work of the geometry tail */
 #define SCSFM_DEBUG_X5 32768u /* scatter into the LDS window but never flush it */
 
 #define SCSFM_DEBUG_KERNEL_ONLY 16384u /* scsfm_pairs_fwd only, for timing: launch the main kernel alone (the

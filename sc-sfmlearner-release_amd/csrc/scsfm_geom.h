@@ -366,6 +366,11 @@ constexpr int kWinW = SCSFM_WIN_W, kWinH = SCSFM_WIN_H;  // window of a 64 x 16 
 #endif
 constexpr int kGeomRows = SCSFM_GEOM_ROWS;  // rows per thread of the geometry pass (its tile is 64 x 4 kGeomRows)
 
+template <typename T>
+__device__ __forceinline__ void lds_add(T* p, T v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <typename T, int WW, int WH>
 __device__ __forceinline__ void scatter_taps_window(T (*win)[WW], int wx0, int wy0, T* __restrict__ gplane,
                                                     const Sample<T>& s, T g) {
@@ -373,10 +378,12 @@ __device__ __forceinline__ void scatter_taps_window(T (*win)[WW], int wx0, int w
   const int lx = s.x0 - wx0, ly = s.y0 - wy0;
   if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < WH - 1) {
     // unpredicated: an out-of-image tap has weight 0, and adding 0 leaves its cell at the 0 the flush skips
-    atomicAdd(&win[ly][lx], g * s.w[0]);
-    atomicAdd(&win[ly][lx + 1], g * s.w[1]);
-    atomicAdd(&win[ly + 1][lx], g * s.w[2]);
-    atomicAdd(&win[ly + 1][lx + 1], g * s.w[3]);
+    // (workgroup scope is what an LDS atomic is; it also keeps the compiler from merging these with the global
+    // atomics of the other branch into flat_atomic instructions on a generic pointer, which it otherwise does)
+    lds_add(&win[ly][lx], g * s.w[0]);
+    lds_add(&win[ly][lx + 1], g * s.w[1]);
+    lds_add(&win[ly + 1][lx], g * s.w[2]);
+    lds_add(&win[ly + 1][lx + 1], g * s.w[3]);
   } else {
     scatter_taps(gplane, s, g);
   }

@@ -502,7 +502,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
 #pragma unroll
     for (int k = 0; k < STRIP; ++k) {
       const int ly = strip * STRIP + k, py = py0 + k;
-      if (!(in_x && ly >= 1 && ly <= TH - 2 && py < H)) continue;
+      if (!(in_x && ly >= 1 && ly <= TH - 2 && py < H) || (flags & SCSFM_DEBUG_X4)) continue;
       T gI[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -513,7 +513,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
       st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gd);
     }
     __syncthreads();
-    flush_scatter_window<T, WW, WH>(win, wx0, wy0, g_scatter, W);
+    if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5))) flush_scatter_window<T, WW, WH>(win, wx0, wy0, g_scatter, W);
     __syncthreads();  // `red` is reused
     block_sum<12>(acc, red);
     if (threadIdx.x == 0) {
@@ -789,7 +789,8 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
   dim3 grid;
   if (spec) {
     const size_t npx = (size_t)B * H * W;
-    hipLaunchKernelGGL((pairs_zero_scatter_kernel<T>), dim3(1024, n), dim3(kThreads), 0, stream, pb, npx);
+    if (!kernel_only)
+      hipLaunchKernelGGL((pairs_zero_scatter_kernel<T>), dim3(1024, n), dim3(kThreads), 0, stream, pb, npx);
     grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
     const T r_hint = T(3.0 * w_geom / w_photo);
     if (flags & SCSFM_WITH_SSIM)

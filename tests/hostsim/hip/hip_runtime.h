@@ -205,6 +205,10 @@ template <class T> static inline T __shfl(T v, int l, int = 64) { return hostsim
 
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 static inline float atomicAdd(float* p, double v) { float o = *p; *p = o + (float)v; return o; }
+// scoped atomics (fibres never run concurrently, so a plain read-modify-write is atomic)
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __HIP_MEMORY_SCOPE_AGENT 3
+template <class T> static inline T __hip_atomic_fetch_add(T* p, T v, int, int) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 static inline void __threadfence() {}
 
