@@ -319,7 +319,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
   constexpr int TH = Tile<T>::kH, STRIP = TH / (kThreads / kWave);
   __shared__ V2 sXY[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];
   __shared__ T sG[kSsim ? 3 : 1][kSsim ? TH : 1][kSsim ? kTileW : 1];  // 1/9 (g_mu_y, g_E[y^2], g_E[xy]), one colour
-  __shared__ double red[kSpec ? 12 * (kThreads / kWave) : 1];
+  __shared__ double red[kSpec ? (3 + 12) * (kThreads / kWave) : 1];  // the two block sums use disjoint parts
   // kSpec: staging window of the geometry tail's scatter (its height follows the tile's)
   constexpr int WW = kWinW, WH = kWinH * TH / kTileH;
   __shared__ T win[kSpec ? WH : 1][kSpec ? WW : 1];
@@ -355,6 +355,8 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
   T mq[STRIP];    // mask of the owned pixel
   T bsum[STRIP];  // sum_c blend_c of the owned pixel
   T acc_g = T(0), acc_m = T(0);  // kSpec: forward sums over the pixels this block owns
+  int bx0 = 1 << 30, bx1 = -(1 << 30), by0 = 1 << 30, by1 = -(1 << 30);
+  __shared__ int sBox[kSpec ? kThreads / kWave : 1][4];
   V2 cen[kSsim ? 1 : STRIP][kSsim ? 1 : 3];
   // kSpec: dL/d(warped colour c) of the owned pixels waits for the geometry tail -- parked in the LDS tile of
   // colour c, which is dead by the time that gradient exists (every thread only touches its own slots); in
@@ -393,8 +395,22 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
     coef[k] = a * mq[k] * (with_mask ? (T(1) - ddk) : T(1));
     bsum[k] = T(0);
     if constexpr (kSpec) {
-      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) { acc_g += ddk * mq[k]; acc_m += mq[k]; }
+      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) {
+        acc_g += ddk * mq[k]; acc_m += mq[k];
+        if (mq[k] != T(0)) {  // this pixel will scatter: where its north-west tap lies
+          bx0 = s.x0 < bx0 ? s.x0 : bx0; bx1 = s.x0 > bx1 ? s.x0 : bx1;
+          by0 = s.y0 < by0 ? s.y0 : by0; by1 = s.y0 > by1 ? s.y0 : by1;
+        }
+      }
     }
+  }
+  if constexpr (kSpec) {  // bounding box of the block's scatter footprint: per wave here, met in the tail
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+      const int a0 = __shfl_xor(bx0, o), a1 = __shfl_xor(bx1, o), c0 = __shfl_xor(by0, o), c1 = __shfl_xor(by1, o);
+      bx0 = a0 < bx0 ? a0 : bx0; bx1 = a1 > bx1 ? a1 : bx1; by0 = c0 < by0 ? c0 : by0; by1 = c1 > by1 ? c1 : by1;
+    }
+    if (col == 0) { sBox[strip][0] = bx0; sBox[strip][1] = bx1; sBox[strip][2] = by0; sBox[strip][3] = by1; }
   }
   // ---- phase 1b: ring ------------------------------------------------------------------------
   if constexpr (kSsim) {
@@ -494,33 +510,53 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
     // scatter plane and the pose partials are all scaled by a = g_photo / (3 S_m) when they are combined)
     T* __restrict__ g_dense = pa.gbuf + kPlaneDense * gplane + (size_t)b * plane;
     T* __restrict__ g_scatter = pa.gbuf + kPlaneScatter * gplane + (size_t)b * plane;
+    // the window goes where the block's pixels land: around the bounding box of their north-west taps (known
+    // since the warp), centred on it when it is larger than the window (the rest falls back to global atomics)
     int wx0, wy0;
-    window_origin<T, WW, WH>(bc, ox + kTileW / 2, oy + TH / 2, tgt_depth, H, W, flags, wx0, wy0);
-    T acc[12];
+    {
+      int x0 = sBox[0][0], x1 = sBox[0][1], y0 = sBox[0][2], y1 = sBox[0][3];
+#pragma unroll
+      for (int w = 1; w < kThreads / kWave; ++w) {
+        x0 = sBox[w][0] < x0 ? sBox[w][0] : x0; x1 = sBox[w][1] > x1 ? sBox[w][1] : x1;
+        y0 = sBox[w][2] < y0 ? sBox[w][2] : y0; y1 = sBox[w][3] > y1 ? sBox[w][3] : y1;
+      }
+      if (x0 > x1) { x0 = x1 = 0; y0 = y1 = 0; }  // nothing scatters
+      const int ex = x1 - x0 + 2, ey = y1 - y0 + 2;  // cells touched (each pixel reaches one past its tap)
+      wx0 = ex <= WW ? x0 - (WW - ex) / 2 : (x0 + x1 + 1) / 2 - WW / 2;
+      wy0 = ey <= WH ? y0 - (WH - ey) / 2 : (y0 + y1 + 1) / 2 - WH / 2;
+    }
+    T acc[12], gd[STRIP];
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = T(0);
 #pragma unroll
     for (int k = 0; k < STRIP; ++k) {
       const int ly = strip * STRIP + k, py = py0 + k;
+      gd[k] = T(0);
       if (!(in_x && ly >= 1 && ly <= TH - 2 && py < H) || (flags & SCSFM_DEBUG_X4)) continue;
       T gI[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         if constexpr (kSsim) gI[c] = reinterpret_cast<const T*>(&sXY[c][0][0])[ly * kTileW + col]; else gI[c] = gI_reg[k][c];
       }
-      const T gd = geom_pixel<T, WW, WH>(bc, px, py, in_d[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win,
-                                         wx0, wy0, g_scatter, acc);
-      st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gd);
+      gd[k] = geom_pixel<T, WW, WH>(bc, px, py, in_d[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
+                                    wy0, g_scatter, acc);
     }
-    __syncthreads();
-    if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5))) flush_scatter_window<T, WW, WH>(win, wx0, wy0, g_scatter, W);
-    __syncthreads();  // `red` is reused
-    block_sum<12>(acc, red);
+    // A barrier waits for every outstanding global store / atomic of the wave, so everything that writes to
+    // global memory comes after the last barrier: the round trips of the dense stores and of the window's
+    // atomics then overlap with the next workgroup instead of stalling this one.
+    block_sum<12>(acc, red + 3 * (kThreads / kWave));  // (its barrier also orders the scatter's LDS atomics before the flush)
     if (threadIdx.x == 0) {
       double* o = pa.gPp + 12 * ((size_t)(b * nby + blk.y) * nbx + blk.x);
 #pragma unroll
       for (int i = 0; i < 12; ++i) o[i] = double(acc[i]);
     }
+#pragma unroll
+    for (int k = 0; k < STRIP; ++k) {
+      const int ly = strip * STRIP + k, py = py0 + k;
+      if (in_x && ly >= 1 && ly <= TH - 2 && py < H && !(flags & SCSFM_DEBUG_X4))
+        st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gd[k]);
+    }
+    if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5))) flush_scatter_window<T, WW, WH>(win, wx0, wy0, g_scatter, W);
   }
 }
 
