@@ -245,6 +245,9 @@ def main():
     ap.add_argument("--kernel-iters", type=int, default=30)
     ap.add_argument("--e2e-steps", type=int, default=20, help="timed whole-training steps with the nets (0 = skip)")
     ap.add_argument("--e2e-warmup", type=int, default=5)
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1: time the step as a HIP-graph replay (scsfm_hip.graphs.GraphedStep; the eager figure is "
+                         "reported beside it), 0: eager launches only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -277,19 +280,45 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = hot_path_step(LF, x, flags)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = hot_path_step(LF, x, flags)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-    loss, photo, smooth, geom = (float(v) for v in out)
+    def timed(step_fn):
+        """W untimed + exactly K timed steps between barrier + synchronize; max over ranks."""
+        for _ in range(args.warmup):
+            o = step_fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            o = step_fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        return dt, o
+
+    # eager: every kernel launched from Python each step (the way train.py calls the loss functions)
+    eager_elapsed, out = timed(lambda: hot_path_step(LF, x, flags))
+    eager_vals = [float(v.detach()) for v in out]
+    del out  # nothing may keep the eager step's autograd graph (and its stream-bound AccumulateGrad nodes) alive
+    import gc
+    gc.collect()
+    elapsed, launch = eager_elapsed, "eager launches from Python"
+    graph_err = None
+    if args.graph:
+        # the same step captured once into a HIP graph and replayed: identical kernels and results, one launch
+        try:
+            from scsfm_hip.graphs import GraphedStep
+            gs = GraphedStep(lambda: hot_path_step(LF, x, flags))
+            elapsed, out = timed(gs.replay)
+            launch = "HIP graph replay of the captured step (torch.cuda.CUDAGraph)"
+            gvals = [float(v.detach()) for v in out]
+            assert all(abs(a - b) <= 1e-6 * max(1.0, abs(b)) for a, b in zip(gvals, eager_vals)), (gvals, eager_vals)
+        except Exception as exc:  # keep the eager measurement, say why the graph leg is missing
+            graph_err = f"{type(exc).__name__}: {exc}"
+            elapsed, gvals = eager_elapsed, eager_vals
+    else:
+        gvals = eager_vals
+    loss, photo, smooth, geom = gvals
 
     n_px = args.batch * args.height * args.width
     ms_per_step = elapsed / args.steps * 1e3
@@ -332,8 +361,11 @@ def main():
             "config": {"workload": f"configs[1]: {args.dataset} {args.height}x{args.width}, batch {args.batch}/GPU, "
                                    f"{args.n_ref} refs (seq {args.n_ref + 1}), ssim+mask+auto-mask, zeros padding, "
                                    f"1 scale, {args.depth} synthetic depth",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world} (batch shards, no loss-path collective)"},
+                       "global_batch": world * args.batch, "parallelism": f"dp{world} (batch shards, no loss-path collective)",
+                       "launch": launch},
             "warp_loss_ms_per_step": round(ms_per_step, 4),
+            "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
+            "graph_error": graph_err,
             "step_algorithmic_GBs": round(step_bytes(n_px, args.n_ref) / (elapsed / args.steps) / 1e9, 1),
             "step_frac_of_hbm_peak": round(step_bytes(n_px, args.n_ref) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "kernel_us": {k: round(v * 1e6, 2) for k, v in kt.items()},

@@ -57,6 +57,7 @@ class CLib:
         self.path = path
         self._dll = ctypes.CDLL(path)
         self.decls = parse_header()
+        self._fn = {}
         for name, (ret, argtypes) in self.decls.items():
             try:
                 fn = getattr(self._dll, name)
@@ -64,18 +65,19 @@ class CLib:
                 raise ScsfmError(f"{path} does not export {name} (declared in {HEADER})") from e
             fn.restype = ret
             fn.argtypes = argtypes
+            self._fn[name] = fn
         if self._dll.scsfm_abi_version() != 1:
             raise ScsfmError(f"{path}: ABI version mismatch")
 
     def call(self, name, *args):
         """Invoke an int-returning entry point; raise on a non-zero status."""
-        rc = getattr(self._dll, name)(*args)
+        rc = self._fn[name](*args)
         if rc != 0:
             kind = "rejected argument" if rc == -1 else "hipError_t"
             raise ScsfmError(f"{name} failed with status {rc} ({kind})")
 
     def size(self, name, *args):
-        return int(getattr(self._dll, name)(*args))
+        return int(self._fn[name](*args))
 
 
 _lock = threading.Lock()
