@@ -512,7 +512,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
     T* __restrict__ g_scatter = pa.gbuf + kPlaneScatter * gplane + (size_t)b * plane;
     // the window goes where the block's pixels land: around the bounding box of their north-west taps (known
     // since the warp), centred on it when it is larger than the window (the rest falls back to global atomics)
-    int wx0, wy0;
+    int wx0, wy0, cx0, cy0, cx1, cy1;  // window origin; cells of the window the taps can reach
     {
       int x0 = sBox[0][0], x1 = sBox[0][1], y0 = sBox[0][2], y1 = sBox[0][3];
 #pragma unroll
@@ -524,6 +524,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
       const int ex = x1 - x0 + 2, ey = y1 - y0 + 2;  // cells touched (each pixel reaches one past its tap)
       wx0 = ex <= WW ? x0 - (WW - ex) / 2 : (x0 + x1 + 1) / 2 - WW / 2;
       wy0 = ey <= WH ? y0 - (WH - ey) / 2 : (y0 + y1 + 1) / 2 - WH / 2;
+      cx0 = x0 - wx0; cx1 = x1 + 1 - wx0; cy0 = y0 - wy0; cy1 = y1 + 1 - wy0;
     }
     T acc[12], gd[STRIP];
 #pragma unroll
@@ -556,7 +557,8 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
       if (in_x && ly >= 1 && ly <= TH - 2 && py < H && !(flags & SCSFM_DEBUG_X4))
         st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gd[k]);
     }
-    if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5))) flush_scatter_window<T, WW, WH>(win, wx0, wy0, g_scatter, W);
+    if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5)))
+      flush_scatter_region<T, WW, WH>(win, wx0, wy0, cx0, cy0, cx1, cy1, g_scatter, W);
   }
 }
 
