@@ -301,10 +301,16 @@ __device__ __forceinline__ unsigned pairs_to_run(const PairBatch<T>& pb, int npa
 #define SCSFM_PHOTO_BLOCKS 3
 #endif
 // One tile (blk = logical tile of an nbx x nby x (pairs * B) tiling).
-template <typename T, bool kSsim, bool kSpec>
+// kFlags: kRuntimeFlags = obey `flags_arg`; any other value = the flag word as a compile-time constant (the
+// configuration every training run uses gets its own instantiation: its uniform branches fold away and the
+// scheduler sees longer straight-line blocks).
+constexpr unsigned kRuntimeFlags = 0xffffffffu;
+constexpr unsigned kTrainFlags = SCSFM_WITH_SSIM | SCSFM_WITH_MASK | SCSFM_WITH_AUTO_MASK;  // zeros padding
+template <typename T, bool kSsim, bool kSpec, unsigned kFlags = kRuntimeFlags>
 __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, const PairBatch<T>& pb, int B, int H,
-                                           int W, unsigned flags, const T* __restrict__ g_photo,
+                                           int W, unsigned flags_arg, const T* __restrict__ g_photo,
                                            const T* __restrict__ g_geom, T r_hint) {
+  const unsigned flags = kFlags == kRuntimeFlags ? flags_arg : kFlags;
   const int pair = blk.z / B, b = blk.z - pair * B;
   const PairArgs<T>& pa = pb.p[pair];
   const T* __restrict__ tgt_img = pa.tgt_img;
@@ -563,10 +569,11 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
 }
 
 // The speculative forward: one tile per workgroup, XCD-aware order.
-template <typename T, bool kSsim>
+template <typename T, bool kSsim, unsigned kFlags = kRuntimeFlags>
 __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) void pair_fwd_spec_kernel(PairBatch<T> pb, int B, int H, int W,
                                                                                   unsigned flags, T r_hint) {
-  photo_tile<T, kSsim, true>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, pb, B, H, W, flags, nullptr, nullptr, r_hint);
+  photo_tile<T, kSsim, true, kFlags>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, pb, B, H, W, flags, nullptr, nullptr,
+                                     r_hint);
 }
 
 // Pass A of the backward.  Launched with a small persistent grid that walks the tiles: when the speculative
@@ -831,7 +838,10 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
       hipLaunchKernelGGL((pairs_zero_scatter_kernel<T>), dim3(1024, n), dim3(kThreads), 0, stream, pb, npx);
     grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
     const T r_hint = T(3.0 * w_geom / w_photo);
-    if (flags & SCSFM_WITH_SSIM)
+    if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags)
+      hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true, kTrainFlags>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags,
+                         r_hint);
+    else if (flags & SCSFM_WITH_SSIM)
       hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags, r_hint);
     else
       hipLaunchKernelGGL((pair_fwd_spec_kernel<T, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags, r_hint);
