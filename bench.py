@@ -82,7 +82,8 @@ def pmc_traffic(args, n_pairs):
         return None
     try:
         d = json.load(open(path))
-        k = d[f"scsfm::pair_fwd_spec_kernel<float, true>|gz{n_pairs * args.batch}"]
+        gz = n_pairs * args.batch
+        k = d.get(f"scsfm::pair_fwd_spec_kernel<float, true, 7u>|gz{gz}") or d[f"scsfm::pair_fwd_spec_kernel<float, true>|gz{gz}"]
         return int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
     except (KeyError, ValueError):
         return None
@@ -333,7 +334,7 @@ def main():
     # two depth gradients are written once and read-modify-written once (16 B/px).
     spec_bytes = n_pairs * 48 * n_px
     achieved = spec_bytes / kt["spec_kernel_only"] / 1e9
-    roofline = {"bound": "hbm", "kernel": f"pair_fwd_spec_kernel<float,true> ({n_pairs} pair-directions per launch)",
+    roofline = {"bound": "hbm", "kernel": f"pair_fwd_spec_kernel<float,true,7u> ({n_pairs} pair-directions per launch)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, n_pairs),
                 "algorithmic_bytes_per_launch": spec_bytes, "avg_launch_us": round(kt["spec_kernel_only"] * 1e6, 2)}

@@ -16,9 +16,9 @@ echo "=== bench configs[3] loss path (batch 8) and configs[4] (NYU 256x320, 4 re
 timeout 600 python bench.py --steps 30 --warmup 5 --batch 8 --cpu-seconds 0 --e2e-steps 0 > $O/bench_${TAG}_cfg3.json 2>> $O/bench_$TAG.err; cut -c1-330 $O/bench_${TAG}_cfg3.json
 timeout 600 python bench.py --steps 30 --warmup 5 --dataset nyu --height 256 --width 320 --n-ref 4 --batch 16 --cpu-seconds 0 --e2e-steps 0 > $O/bench_${TAG}_cfg4.json 2>> $O/bench_$TAG.err; cut -c1-330 $O/bench_${TAG}_cfg4.json
 cd /tmp
-echo "=== rocprof kernel trace"; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --e2e-steps 0 --kernel-iters 3 > $O/rocprof_$TAG.log 2>&1; echo "rc=$?"
+echo "=== rocprof kernel trace"; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --e2e-steps 0 --graph 0 --kernel-iters 3 > $O/rocprof_$TAG.log 2>&1; echo "rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
-  echo "=== rocprof pmc $C"; timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/prof_$TAG -o pmc_$C -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --e2e-steps 0 --kernel-iters 2 > $O/rocprof_${TAG}_$C.log 2>&1; echo "rc=$?"
+  echo "=== rocprof pmc $C"; timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/prof_$TAG -o pmc_$C -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --e2e-steps 0 --graph 0 --kernel-iters 2 > $O/rocprof_${TAG}_$C.log 2>&1; echo "rc=$?"
 done
 cd $R
 python tools/rocprof_summary.py $O/prof_$TAG/trace_results.db | grep -v "at::native\|rocclr" | head -20
