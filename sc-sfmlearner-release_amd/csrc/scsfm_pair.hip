@@ -3,13 +3,20 @@
 // valid / auto mask, clamped L1, SSIM (loss_functions.py:11-42), depth inconsistency, the
 // self-discovered weight mask and the two masked means (loss_functions.py:123-129).
 //
-// Forward  : pair_fwd_kernel  -> per-block partial sums {sum photo*m, sum geom*m, sum m}
+// Forward, no backward to follow (validation):
+//            pair_fwd_kernel  -> per-block partial sums {sum photo*m, sum geom*m, sum m}
 //            pair_finalize_kernel -> the two gated losses + the backward coefficients (on device;
 //            the reference's `if mask.sum() > 10000` host sync disappears)
-// Backward : pair_bwd_kernel recomputes the warp inside the tile (nothing but 3 sums is kept from
-//            the forward), runs the SSIM backward as a 3x3 gather with reflection multiplicities,
-//            writes dL/d tgt_depth densely, scatters dL/d ref_depth with fp32 atomics and reduces
-//            dL/d(A|c) per batch element; pose_bwd_kernel finishes dL/d pose.
+// Forward of a training step (speculative: the upstream gradients are assumed to stand in the ratio of the
+// loss weights):
+//            pair_fwd_spec_kernel -> the same partial sums AND the whole backward up to the scalar the
+//            reduction supplies: tiled SSIM backward, then the geometry tail writes this pair's dense
+//            dL/d tgt_depth plane, scatters its dL/d ref_depth plane (LDS window + fp32 atomics) and
+//            leaves per-block partials of dL/d(A|c)
+// Backward : pair_bwd_photo_kernel + pair_bwd_geom_kernel are the same two passes with the true coefficients;
+//            they run only when the speculation does not hold (a guard at their top otherwise);
+//            pairs_pose_reduce_kernel finishes dL/d pose, pairs_combine_kernel scales the private planes
+//            and stores their sums into the callers' gradient buffers.
 //
 // Tiling (gfx950): 256 threads = 4 waves; a wave spans 64 consecutive pixels of a row (256 B
 // coalesced rows), each thread owns a vertical strip of the 64 x TH tile, so the SSIM window sums
@@ -255,21 +262,23 @@ __global__ void pair_refinalize_kernel(double* __restrict__ sums, T* __restrict_
 //
 // Recomputes the warp inside the tile (nothing but 3 sums is kept from the forward), runs the SSIM
 // backward -- forward statistics at every pixel of the 64 x TH domain, then the transpose of
-// (reflect-pad + box) as a separable 3x3 gather -- and writes four planes for the 62 x (TH-2)
-// interior: gbuf[c] = dL/dI_w,c (c = 0..2), gbuf[3] = dL/d diff_depth.  Pass B consumes them.
-// Splitting here keeps both halves at a register budget that sustains 3-4 waves per SIMD; fused, the
-// kernel needed 256 VGPRs (1 wave per SIMD) and could not hide its gather latency.  (This half is
-// bounded to 3 waves per SIMD: at 4 it spills 52 B per lane, and that scratch traffic doubled its
-// WRITE_SIZE and cost 9 % -- profiles/r01c.)
+// (reflect-pad + box) as a separable 3x3 gather -- and, as pass A of the backward proper, writes four
+// planes for the 62 x (TH-2) interior: gbuf[c] = dL/dI_w,c (c = 0..2), gbuf[3] = dL/d diff_depth, which
+// pass B consumes.  (History: a first fused A+B kernel needed 256 VGPRs -- 1 wave per SIMD -- because it
+// carried the sampling state of its pixels across the SSIM phases; the speculative forward below fuses
+// them again by carrying only the depth and re-projecting in the tail.  The tile code is bounded to
+// 3 waves per SIMD: at 4 it spills 52 B per lane, and that scratch traffic doubled its WRITE_SIZE and
+// cost 9 % -- profiles/r01c.)
 // ==========================================================================================
 //
-// kSpec = true is the SPECULATIVE FORWARD: the same kernel run as the forward pass, with unit photo
+// kSpec = true is the SPECULATIVE FORWARD: the same tile code run as the forward pass, with unit photo
 // coefficient and the geometry / photo coefficient ratio r = 3 w_geom / w_photo the caller expects the
 // upstream gradients to have (the loss weights are constants of a training run, train.py:268).  It
-// produces the three sums of the forward AND the four gradient planes up to the common factor
-// a = g_photo / (3 S_m), which is only known after the reduction; the backward then starts directly at
-// pass B with that factor.  If the upstream gradients turn out different (spec_valid), pass A is
-// re-run normally.  This removes one full warp + SSIM recomputation per pair-direction.
+// produces the three sums of the forward AND carries on through pass B (the geometry tail) for the pixels
+// it owns: dL/d(warped colour) waits in LDS, the tail re-projects the pixel from the depth it kept,
+// gathers, and writes the pair's dense / scatter planes and pose partials, all up to the common factor
+// a = g_photo / (3 S_m), which is only known after the reduction and is applied when the planes are
+// combined.  If the upstream gradients turn out different (spec_valid), passes A and B run normally.
 template <typename T>
 __device__ __forceinline__ bool spec_valid(const double* __restrict__ sums, const T* __restrict__ g_photo,
                                            const T* __restrict__ g_geom) {
