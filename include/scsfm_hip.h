@@ -54,7 +54,8 @@ extern "C" {
 #define SCSFM_OK 0
 #define SCSFM_ERR_ARG (-1)
 
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any change of a signature or of what an entry point does with its
+ * buffers (2: the batched backwards store their depth gradients; scratch holds six planes). */
 int scsfm_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
