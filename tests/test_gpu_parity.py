@@ -302,3 +302,35 @@ def test_legacy_inverse_warp(IW, dev):
     ov = torch.maximum(xn.abs(), yn.abs()) <= 1
     assert (valid.cpu() != ov).double().mean() <= 1e-3
     assert_close_frac(w.cpu().numpy(), ow.numpy(), atol=3e-4, max_bad_frac=2e-3)
+
+
+def test_speculation_holding_failing_and_absent_agree(dev):
+    """The three ways a training step can run on the device -- the speculative forward's results stand (hint =
+    the upstream weights), they do not (wrong hint: the backward's own passes run behind their guards, with real
+    concurrency, which the host simulation cannot show), no speculation at all -- give the same losses and the
+    same gradients at full size."""
+    from scsfm_hip import _lib, capi, synth
+    lib = _lib.get()
+    d = synth.make_batch(6, 256, 832, n_ref=2, seed=11, depth="smooth", image="smooth", dataset="kitti")
+    to = lambda t: t.to(dev)
+    tgt, K, refs = to(d["tgt_img"]), to(d["intrinsics"]), [to(t) for t in d["ref_imgs"]]
+    tds, rds = [to(d["tgt_depth"][0])], [[to(r[0])] for r in d["ref_depths"]]
+    ps, pis = [to(p) for p in d["poses"]], [to(p) for p in d["poses_inv"]]
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    w_photo, w_geom = 0.3, 1.1
+    gp, gg = torch.full((1,), w_photo, device=dev), torch.full((1,), w_geom, device=dev)
+    import numpy as np
+    exact = (float(np.float32(w_photo)), float(np.float32(w_geom)))
+    results = {}
+    for name, hint in (("holds", exact), ("fails", (1.0, 0.5)), ("absent", None)):
+        photo, geom, _, ws = capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, hint=hint)
+        g_td, g_rd, g_p, g_pi = capi.photo_geometry_bwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, ws, gp, gg)
+        results[name] = (float(photo), float(geom), [g_td[0]] + [r[0] for r in g_rd] + list(g_p) + list(g_pi))
+    ref = results["absent"]
+    for name in ("holds", "fails"):
+        got = results[name]
+        assert abs(got[0] - ref[0]) <= 1e-6 and abs(got[1] - ref[1]) <= 1e-6, name
+        for a, b in zip(got[2], ref[2]):
+            scale = float(b.abs().max())
+            # same arithmetic up to the order of the scatter's atomics and where the scalar factor is applied
+            assert float((a - b).abs().max()) <= 2e-4 * scale, (name, scale)
