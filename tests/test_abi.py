@@ -62,3 +62,13 @@ def test_product_loader_never_points_at_the_simulator():
     assert _lib.LIB_PATH.endswith(os.path.join("scsfm_hip", "libscsfm_hip.so"))
     src = open(_lib.__file__).read()
     assert "hostsim" not in src and "oracle" not in src
+
+
+def test_graph_capture_needs_a_device():
+    """scsfm_hip.graphs has no CPU mode either."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    from scsfm_hip.graphs import GraphedStep
+    with pytest.raises(RuntimeError):
+        GraphedStep(lambda: None)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build tuning variants of libscsfm_hip.so into variants/ (git-ignored; travels to the GPU box).
 #   bash tools/build_variants.sh NAME "-DSCSFM_WIN_W=80 -DSCSFM_WIN_H=24" [NAME2 "flags2" ...]
-# Use one with  SCSFM_HIP_LIB=$PWD/variants/NAME.so python tools/ablate_geom.py
+# Use one with  SCSFM_HIP_LIB=$PWD/variants/NAME.so python tools/ablate_tail.py
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p variants
