@@ -273,6 +273,16 @@ int scsfm_augment_u8_f32(int n_frames, int frames_per_sample, int H, int W, cons
                          const int* params, const int* htab, const int* vtab, const float* lut, float* out,
                          void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Measurement hook (bench.py's roofline): between scsfm_profile_begin(n) and scsfm_profile_end, the first n
+ * launches of the dominant kernel (the speculative forward of scsfm_pairs_fwd) are bracketed by HIP events
+ * recorded on the stream they are launched on -- i.e. inside real steps, with whatever the other kernels of
+ * the step leave in the caches.  scsfm_profile_end waits for them and reports the mean and the minimum
+ * duration in microseconds and how many launches were bracketed.  Not thread-safe; off by default.
+ * --------------------------------------------------------------------------------------------- */
+int scsfm_profile_begin(int n);
+int scsfm_profile_end(double* mean_us, double* min_us, int* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -807,6 +807,20 @@ __global__ __launch_bounds__(kThreads) void pairs_zero_scatter_kernel(PairBatch<
 // ------------------------------------------------------------------------------------------
 // Host side of the C ABI.
 // ------------------------------------------------------------------------------------------
+// scsfm_profile_begin / _end: event pairs around launches of the speculative forward.
+struct ProfileState {
+  hipEvent_t* start = nullptr;
+  hipEvent_t* stop = nullptr;
+  int n = 0, used = 0;
+};
+static ProfileState g_profile;
+
+static void profile_release() {
+  for (int i = 0; i < g_profile.n; ++i) { (void)hipEventDestroy(g_profile.start[i]); (void)hipEventDestroy(g_profile.stop[i]); }
+  delete[] g_profile.start; delete[] g_profile.stop;
+  g_profile = ProfileState();
+}
+
 template <typename T>
 static PairArgs<T> make_pair_args(const scsfm_pair_desc& d, int B, int H, int W, void* shared_scratch, int idx) {
   const PairWs l = pair_ws_layout(B, H, W);
@@ -847,6 +861,8 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
       hipLaunchKernelGGL((pairs_zero_scatter_kernel<T>), dim3(1024, n), dim3(kThreads), 0, stream, pb, npx);
     grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
     const T r_hint = T(3.0 * w_geom / w_photo);
+    const bool timed = g_profile.used < g_profile.n;
+    if (timed) (void)hipEventRecord(g_profile.start[g_profile.used], stream);
     if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags)
       hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true, kTrainFlags>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags,
                          r_hint);
@@ -854,6 +870,7 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
       hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags, r_hint);
     else
       hipLaunchKernelGGL((pair_fwd_spec_kernel<T, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags, r_hint);
+    if (timed) (void)hipEventRecord(g_profile.stop[g_profile.used++], stream);
   } else {
     grid = dim3(ceil_div(W, kTileW), ceil_div(H, Tile<T>::kH), n * B);
     if (flags & SCSFM_WITH_SSIM)
@@ -978,6 +995,40 @@ static scsfm_pair_desc one_desc(const T* tgt_img, const T* ref_img, const T* tgt
 }  // namespace scsfm
 
 extern "C" {
+
+int scsfm_profile_begin(int n) {
+  scsfm::profile_release();
+  if (n <= 0) return n == 0 ? SCSFM_OK : SCSFM_ERR_ARG;
+  scsfm::g_profile.start = new hipEvent_t[n];
+  scsfm::g_profile.stop = new hipEvent_t[n];
+  for (int i = 0; i < n; ++i) {
+    if (hipEventCreate(&scsfm::g_profile.start[i]) != hipSuccess || hipEventCreate(&scsfm::g_profile.stop[i]) != hipSuccess) {
+      scsfm::g_profile.n = i;  // (what exists so far is released)
+      scsfm::profile_release();
+      return (int)hipGetLastError();
+    }
+    scsfm::g_profile.n = i + 1;
+  }
+  return SCSFM_OK;
+}
+
+int scsfm_profile_end(double* mean_us, double* min_us, int* count) {
+  if (!mean_us || !min_us || !count) return SCSFM_ERR_ARG;
+  double sum = 0.0, mn = 0.0;
+  const int used = scsfm::g_profile.used;
+  for (int i = 0; i < used; ++i) {
+    float ms = 0.0f;
+    (void)hipEventSynchronize(scsfm::g_profile.stop[i]);
+    (void)hipEventElapsedTime(&ms, scsfm::g_profile.start[i], scsfm::g_profile.stop[i]);
+    sum += 1e3 * ms;
+    mn = (i == 0 || 1e3 * ms < mn) ? 1e3 * ms : mn;
+  }
+  *mean_us = used ? sum / used : 0.0;
+  *min_us = mn;
+  *count = used;
+  scsfm::profile_release();
+  return SCSFM_OK;
+}
 
 size_t scsfm_pair_bwd_scratch_bytes(int B, int H, int W) {
   if (B <= 0 || H < 2 || W < 2) return 0;
