@@ -260,12 +260,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the loss path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # SCSFM_BENCH_SHARED_GPU=1 (testing only): every rank uses device 0 and the ranks talk over gloo, so that the
+    # multi-process control flow can be exercised on a 1-GPU box; its numbers mean nothing.
+    shared_gpu = os.environ.get("SCSFM_BENCH_SHARED_GPU") == "1"
+    dev_index = 0 if shared_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        if shared_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
 
     import loss_functions as LF
     from scsfm_hip import _lib
@@ -363,7 +370,7 @@ def main():
     e2e = None
     if args.e2e_steps > 0:
         try:
-            e2e = e2e_train(args, device, world, local_rank, barrier)
+            e2e = e2e_train(args, device, world, dev_index, barrier)
         except Exception as exc:  # the hot-path figures above stay valid; say what happened
             e2e = {"error": f"{type(exc).__name__}: {exc}"}
 
