@@ -146,6 +146,9 @@ typedef struct scsfm_pair_desc {
   void* g_pose;
   void* gbuf; /* NULL, or scsfm_pair_bwd_scratch_bytes(B,H,W) bytes private to this pair, alive from the
                  forward to the backward: enables the speculative forward (see scsfm_pair_fwd_spec) */
+  void* total; /* read from d[0] only, may be NULL: 2 elements (device, store) that the forward fills with the
+                  sums over all n pair-directions of out[0] (photo) and out[1] (geometry) -- what
+                  compute_photo_and_geometry_loss returns (loss_functions.py:89-92) -- without a launch of its own */
 } scsfm_pair_desc;
 
 int scsfm_pairs_fwd_f32(int n, const scsfm_pair_desc* d, int B, int H, int W, const float* intrinsics,
@@ -242,8 +245,8 @@ int scsfm_masked_mean_bwd_f64(int B, int C, int Cm, int HW, const double* mask, 
                               const double* g, double* g_diff, void* stream);
 
 /* compute_smooth_loss (loss_functions.py:154-159): n frames per call.  depths / imgs / g_depths / edges
- * are HOST arrays of n DEVICE pointers; ws = n * scsfm_smooth_ws_bytes(B,H,W) bytes; out[n] (device,
- * store) holds one loss per frame; g_depths[i] is STORED (every pixel is written, no zero-fill needed;
+ * are HOST arrays of n DEVICE pointers; ws = n * scsfm_smooth_ws_bytes(B,H,W) bytes; out[n + 1] (device,
+ * store) holds one loss per frame and, in out[n], their sum (what compute_smooth_loss returns); g_depths[i] is STORED (every pixel is written, no zero-fill needed;
  * the single-frame scsfm_smooth_bwd accumulates); a NULL g_depths[i] skips that frame's gradient.
  * edges (may be NULL, as may any entry): per frame a [B,H,W] plane in which the forward leaves each
  * pixel's summed edge terms; given the same plane, the backward is a pure stream (4 B read + 4 B

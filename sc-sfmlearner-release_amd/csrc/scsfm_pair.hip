@@ -84,11 +84,18 @@ __device__ __forceinline__ Sample<T> warp_colours(const BatchConsts<T>& bc, int 
   return s;
 }
 
+// "finalize blocks done" counter of a launch: a word of the first pair's sums block (sums[12..15] are spare).
+template <typename T>
+__device__ __forceinline__ unsigned* finalize_counter(const PairBatch<T>& pb) {
+  return reinterpret_cast<unsigned*>(pb.p[0].sums + 12);
+}
+
 // prep_kernel over every (pair, batch element).
 template <typename T>
 __global__ void pairs_prep_kernel(PairBatch<T> pb, int n, int B, const T* __restrict__ K) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * B) return;
+  if (i == 0) *finalize_counter(pb) = 0u;
   const int pair = i / B, b = i - pair * B;
   prep_one(b, pb.p[pair].pose, K, pb.p[pair].consts);
 }
@@ -230,9 +237,11 @@ __device__ __forceinline__ void publish_losses(double Sp, double Sg, double Sm, 
 
 // One block: reduce the partials in fp64, apply the gates of mean_on_mask, publish the losses and
 // the coefficients the backward multiplies the upstream gradients with.
+// `total` (optional): the sums over all pair-directions of a call of the two losses -- what
+// compute_photo_and_geometry_loss returns -- finished by whichever block comes last, in pair order.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb, int nblocks, double spec,
-                                                                 double w_photo, double w_geom) {
+                                                                 double w_photo, double w_geom, T* total, int first) {
   __shared__ double red[3 * (kThreads / kWave)];
   const PairArgs<T>& pa = pb.p[blockIdx.x];
   const double* __restrict__ partials = pa.partials;
@@ -246,6 +255,19 @@ __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb
   if (threadIdx.x == 0) {
     publish_losses(v[0], v[1], v[2], sums, out);
     sums[8] = spec; sums[9] = w_photo; sums[10] = w_geom;
+    if (total) {
+      __threadfence();
+      if (atomicAdd(finalize_counter(pb), 1u) == gridDim.x - 1) {
+        __threadfence();
+        T photo = T(0), geom = T(0);
+        for (unsigned i = 0; i < gridDim.x; ++i) {
+          const volatile T* o = pb.p[i].out;
+          photo += o[0]; geom += o[1];
+        }
+        total[0] = first ? photo : total[0] + photo;
+        total[1] = first ? geom : total[1] + geom;
+      }
+    }
   }
 }
 
@@ -848,7 +870,7 @@ static bool desc_inputs_ok(const scsfm_pair_desc& d) {
 // Forward of up to kMaxPairs pair-directions per launch.  `spec`: every pair has a gbuf and w_photo != 0.
 template <typename T>
 static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags, bool spec,
-                           double w_photo, double w_geom, hipStream_t stream) {
+                           double w_photo, double w_geom, T* total, bool first, hipStream_t stream) {
   PairBatch<T> pb;
   for (int i = 0; i < n; ++i) pb.p[i] = make_pair_args<T>(d[i], B, H, W, nullptr, i);
   const bool kernel_only = (flags & SCSFM_DEBUG_KERNEL_ONLY) != 0;  // profiling: consts are in place already
@@ -880,7 +902,7 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
   }
   if (!kernel_only)
     hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(n), dim3(kThreads), 0, stream, pb, (int)(grid.x * grid.y * B),
-                       spec ? 1.0 : 0.0, spec ? w_photo : 0.0, spec ? w_geom : 0.0);
+                       spec ? 1.0 : 0.0, spec ? w_photo : 0.0, spec ? w_geom : 0.0, total, first ? 1 : 0);
   return launch_status();
 }
 
@@ -898,7 +920,7 @@ static int pairs_fwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
     const bool spec = d[i].gbuf != nullptr && w_photo != 0.0;
     int j = i + 1;
     while (j < n && j - i < kMaxPairs && ((d[j].gbuf != nullptr && w_photo != 0.0) == spec)) ++j;
-    int rc = pairs_fwd_chunk<T>(j - i, d + i, B, H, W, K, flags, spec, w_photo, w_geom, stream);
+    int rc = pairs_fwd_chunk<T>(j - i, d + i, B, H, W, K, flags, spec, w_photo, w_geom, (T*)d[0].total, i == 0, stream);
     if (rc) return rc;
     i = j;
   }
@@ -989,6 +1011,7 @@ static scsfm_pair_desc one_desc(const T* tgt_img, const T* ref_img, const T* tgt
   scsfm_pair_desc d;
   d.tgt_img = tgt_img; d.ref_img = ref_img; d.tgt_depth = tgt_depth; d.ref_depth = ref_depth; d.pose = pose;
   d.ws = ws; d.out = out; d.g_tgt_depth = g_tgt; d.g_ref_depth = g_ref; d.g_pose = g_pose; d.gbuf = gbuf;
+  d.total = nullptr;
   return d;
 }
 

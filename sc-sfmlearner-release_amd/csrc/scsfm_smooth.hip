@@ -20,7 +20,7 @@ constexpr int kSmRows = 4;  // rows per thread
 constexpr int kMaxFrames = 8;
 
 struct SmoothWs {
-  size_t off_img, off_partials, total;
+  size_t off_img, off_partials, off_counter, total;
   int nbx, nby;
 };
 inline SmoothWs smooth_ws_layout(int B, int H, int W) {
@@ -29,7 +29,9 @@ inline SmoothWs smooth_ws_layout(int B, int H, int W) {
   l.nby = ceil_div(H, kSmRows * (kThreads / kWave));
   l.off_img = 0;                                   // double[B][2] = {den_b, L_b}
   l.off_partials = (size_t)B * 2 * sizeof(double); // double[B][nby*nbx][3]
-  l.total = (l.off_partials + (size_t)B * l.nbx * l.nby * 3 * sizeof(double) + 255) & ~(size_t)255;
+  // (+ 256 bytes whose first word is the "finalize blocks done" counter of a multi-frame call)
+  l.off_counter = (l.off_partials + (size_t)B * l.nbx * l.nby * 3 * sizeof(double) + 255) & ~(size_t)255;
+  l.total = l.off_counter + 256;
   return l;
 }
 
@@ -42,6 +44,10 @@ struct SmoothFrame {
 template <typename T>
 struct SmoothBatch {
   SmoothFrame<T> f[kMaxFrames];
+  // optional sum over the frames of a call, finished by whichever finalize block comes last (no extra launch):
+  unsigned* counter;  // in the first frame's workspace; zeroed by the forward kernel
+  T* total;           // nullptr: not wanted
+  int first;          // 1: store (first launch of the call), 0: add
 };
 
 template <typename T>
@@ -125,6 +131,7 @@ __global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(SmoothBatch<T> sb,
       ty_prev = ty;
     }
   }
+  if (sb.total && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *sb.counter = 0u;
   T v[3] = {sd, sx, sy};
   block_sum<3>(v, red);
   if (threadIdx.x == 0) {
@@ -160,6 +167,15 @@ __global__ __launch_bounds__(kThreads) void smooth_finalize_kernel(SmoothBatch<T
     double t = 0;
     for (int w = 0; w < kThreads / kWave; ++w) t += red[w];
     fr.out[0] = T(t);
+    if (sb.total) {  // the last block to get here adds the frames up, in frame order
+      __threadfence();
+      if (atomicAdd(sb.counter, 1u) == gridDim.x - 1) {
+        __threadfence();
+        T sum = T(0);
+        for (unsigned i = 0; i < gridDim.x; ++i) sum += *const_cast<const volatile T*>(sb.f[i].out);
+        sb.total[0] = sb.first ? sum : sb.total[0] + sum;
+      }
+    }
   }
 }
 
@@ -245,7 +261,7 @@ static SmoothFrame<T> make_frame(int B, int H, int W, const void* depth, const v
 
 template <typename T>
 static int smooth_multi_fwd(int n, const void* const* depths, const void* const* imgs, int B, int H, int W, void* ws,
-                            void* const* edges, T* out, void* stream_) {
+                            void* const* edges, T* out, T* total, void* stream_) {
   clear_status();
   if (n < 0 || B <= 0 || H < 2 || W < 2 || (n > 0 && (!depths || !imgs || !ws || !out))) return SCSFM_ERR_ARG;
   for (int i = 0; i < n; ++i)
@@ -258,6 +274,9 @@ static int smooth_multi_fwd(int n, const void* const* depths, const void* const*
     for (int i = 0; i < m; ++i)
       sb.f[i] = make_frame<T>(B, H, W, depths[i0 + i], imgs[i0 + i], (char*)ws + (size_t)(i0 + i) * l.total, out + i0 + i,
                               nullptr, edges ? edges[i0 + i] : nullptr);
+    sb.counter = reinterpret_cast<unsigned*>((char*)ws + (size_t)i0 * l.total + l.off_counter);
+    sb.total = total;
+    sb.first = i0 == 0 ? 1 : 0;
     hipLaunchKernelGGL((smooth_fwd_kernel<T>), dim3(l.nbx, l.nby, m * B), dim3(kThreads), 0, stream, sb, B, H, W);
     hipLaunchKernelGGL((smooth_finalize_kernel<T>), dim3(m), dim3(kThreads), 0, stream, sb, B, H, W, l.nbx * l.nby);
   }
@@ -280,6 +299,7 @@ static int smooth_multi_bwd(int n, const void* const* depths, const void* const*
     for (int i = 0; i < m; ++i)
       sb.f[i] = make_frame<T>(B, H, W, depths[i0 + i], imgs[i0 + i], (char*)ws + (size_t)(i0 + i) * l.total, nullptr,
                               g_depths[i0 + i], edges ? edges[i0 + i] : nullptr);
+    sb.counter = nullptr; sb.total = nullptr; sb.first = 0;
     if (accumulate)
       hipLaunchKernelGGL((smooth_bwd_kernel<T, true>), dim3(l.nbx, l.nby, m * B), dim3(kThreads), 0, stream, sb, B, H, W,
                          g_loss);
@@ -302,7 +322,7 @@ size_t scsfm_smooth_ws_bytes(int B, int H, int W) {
 #define SCSFM_SMOOTH_API(SUF, T)                                                                                     \
   int scsfm_smooth_multi_fwd_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,   \
                                    void* ws, void* const* edges, T* out, void* stream) {                             \
-    return scsfm::smooth_multi_fwd<T>(n, depths, imgs, B, H, W, ws, edges, out, stream);                             \
+    return scsfm::smooth_multi_fwd<T>(n, depths, imgs, B, H, W, ws, edges, out, n > 0 ? out + n : nullptr, stream);   \
   }                                                                                                                  \
   int scsfm_smooth_multi_bwd_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,   \
                                    void* ws, void* const* edges, const T* g_loss, void* const* g_depths,             \
@@ -312,7 +332,7 @@ size_t scsfm_smooth_ws_bytes(int B, int H, int W) {
   int scsfm_smooth_fwd_##SUF(int B, int H, int W, const T* depth, const T* img, void* ws, T* out, void* stream) {    \
     const void* d = depth; const void* im = img;                                                                     \
     if (!depth || !img) return SCSFM_ERR_ARG;                                                                        \
-    return scsfm::smooth_multi_fwd<T>(1, &d, &im, B, H, W, ws, nullptr, out, stream);                                \
+    return scsfm::smooth_multi_fwd<T>(1, &d, &im, B, H, W, ws, nullptr, out, nullptr, stream);                       \
   }                                                                                                                  \
   int scsfm_smooth_bwd_##SUF(int B, int H, int W, const T* depth, const T* img, void* ws, const T* g_loss,           \
                              T* g_depth, void* stream) {                                                             \

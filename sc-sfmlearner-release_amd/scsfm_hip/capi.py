@@ -239,7 +239,7 @@ import functools as _ft
 class PairDesc(_ct.Structure):
     """scsfm_pair_desc of include/scsfm_hip.h."""
     _fields_ = [(n, _ct.c_void_p) for n in ("tgt_img", "ref_img", "tgt_depth", "ref_depth", "pose", "ws", "out",
-                                            "g_tgt_depth", "g_ref_depth", "g_pose", "gbuf")]
+                                            "g_tgt_depth", "g_ref_depth", "g_pose", "gbuf", "total")]
 
 
 @_ft.lru_cache(maxsize=64)
@@ -291,8 +291,9 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
     stride = ws_bytes + (scratch_bytes if spec else 0)  # per pair: workspace, then (speculative) the gbuf planes
     if ws is None:
         ws = torch.empty(n * stride, dtype=torch.uint8, device=tgt_img.device)
-    outs = torch.empty(n, 8, dtype=tgt_img.dtype, device=tgt_img.device)
+    outs = torch.empty(n + 1, 8, dtype=tgt_img.dtype, device=tgt_img.device)  # per pair; last row: the totals
     descs = (PairDesc * n)()
+    descs[0].total = outs.data_ptr() + n * outs.element_size() * 8
     wp, op, esz = ws.data_ptr(), outs.data_ptr(), outs.element_size() * 8
     for j, (ti, ri, dt, dr, po, _, _) in enumerate(pairs):
         d = descs[j]
@@ -304,15 +305,18 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
              float(hint[0]) if spec else 0.0, float(hint[1]) if spec else 0.0, _stream(tgt_img))
     if group is not None:
         import torch.distributed as dist
-        sums = outs[:, 2:5].contiguous()
+        sums = outs[:n, 2:5].contiguous()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-        outs[:, 2:5] = sums
+        outs[:n, 2:5] = sums
         for j in range(n):
             pair_refinalize(lib, (B, H, W), ws[j * stride:j * stride + ws_bytes], outs[j])
     if flags & 16384:  # SCSFM_DEBUG_KERNEL_ONLY (bench.py): nothing was finalised
-        return None, None, outs, ws
-    tot = outs[:, :2].sum(dim=0)  # plain sums over refs, scales and directions (loss_functions.py:89-90)
-    return tot[0], tot[1], outs, ws
+        return None, None, outs[:n], ws
+    if group is not None:
+        tot = outs[:n, :2].sum(dim=0)  # the re-finalised losses
+        return tot[0], tot[1], outs[:n], ws
+    # plain sums over refs, scales and directions (loss_functions.py:89-90), left in the last row by the library
+    return outs[n, 0], outs[n, 1], outs[:n], ws
 
 
 def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws, g_photo,
@@ -380,11 +384,11 @@ def smooth_multi_fwd(lib, depths, imgs, keep_edges=True):
     ws_bytes = _sizes(lib, B, H, W)[2]
     plane_bytes = ((B * H * W * imgs[0].element_size() + 255) // 256) * 256 if keep_edges else 0
     ws = torch.empty(n * (ws_bytes + plane_bytes), dtype=torch.uint8, device=imgs[0].device)
-    outs = torch.empty(n, dtype=imgs[0].dtype, device=imgs[0].device)
+    outs = torch.empty(n + 1, dtype=imgs[0].dtype, device=imgs[0].device)  # one loss per frame, then their sum
     edges = (_ct.c_void_p * n)(*[ws.data_ptr() + n * ws_bytes + i * plane_bytes for i in range(n)]) if keep_edges else None
     lib.call(f"scsfm_smooth_multi_fwd_{_suffix(imgs[0])}", n, _ptr_array(depths), _ptr_array(imgs), B, H, W, _p(ws),
              edges, _p(outs), _stream(imgs[0]))
-    return outs.sum(), ws
+    return outs[n], ws
 
 
 def smooth_multi_bwd(lib, depths, imgs, ws, g_loss, need=None):
