@@ -140,7 +140,7 @@ __device__ __forceinline__ void pose_reduce_one(int b, int nblk, double scale, c
                                                 const T* __restrict__ K, const double* __restrict__ gPp,
                                                 const double* __restrict__ sums, const T* __restrict__ g_photo,
                                                 const T* __restrict__ g_geom, T* __restrict__ gpose) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);  // one wave per call (of a 64-thread or a larger workgroup)
   const bool live = !(T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0));
   double g[12];
 #pragma unroll

@@ -754,42 +754,63 @@ __global__ void pairs_pose_reduce_kernel(PairBatch<T> pb, int B, int nblk_spec, 
 
 // dst[d] (+)= sum_k scale_k * src_k: the dense planes of the pairs whose target depth map dst is and the scatter
 // planes of the pairs that sampled it.  A pair whose passes skipped (both upstream coefficients zero) left its
-// planes untouched and is skipped here too.
+// planes untouched and is skipped here too.  The last row of workgroups (blockIdx.y == nd) does what
+// pairs_pose_reduce_kernel does, one wave per (pair, batch element): dL/dpose rides along for free.
+template <typename T>
+struct CombineSrc {
+  const T* plane;
+  const double* sums;
+  int dst;  // index into CombineBatch::dst
+};
 template <typename T>
 struct CombineBatch {
   T* dst[2 * kMaxPairs];
-  int nsrc[2 * kMaxPairs];
   int store[2 * kMaxPairs];  // 1: dst = sum (the first time a call touches this buffer), 0: dst += sum
-  const T* src[2 * kMaxPairs][2 * kMaxPairs];
-  const double* sums[2 * kMaxPairs][2 * kMaxPairs];
+  int nd, nsrc;
+  CombineSrc<T> src[2 * kMaxPairs];
 };
 
 template <typename T>
 struct alignas(16) Quad { T v[16 / sizeof(T)]; };  // 16-byte vector access
 
 template <typename T>
-__global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T> cb, size_t n,
-                                                                 const T* __restrict__ g_photo,
+__global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T> cb, size_t n, PairBatch<T> pb, int npairs,
+                                                                 int B, int nblk_spec, int nblk_geom,
+                                                                 const T* __restrict__ K, const T* __restrict__ g_photo,
                                                                  const T* __restrict__ g_geom) {
-  constexpr int Q = 16 / sizeof(T);
   const int d = blockIdx.y;
+  if (d == cb.nd) {  // the pose row
+    const int item = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
+    if (item < npairs * B) {
+      const int pair = item / B, b = item - pair * B;
+      const PairArgs<T>& pa = pb.p[pair];
+      const bool spec = spec_valid(pa.sums, g_photo, g_geom);
+      pose_reduce_one(b, spec ? nblk_spec : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K, pa.gPp,
+                      pa.sums, g_photo, g_geom, pa.g_pose);
+    }
+    return;
+  }
+  constexpr int Q = 16 / sizeof(T);
   T* __restrict__ dst = cb.dst[d];
-  const int ns = cb.nsrc[d];
   const bool store = cb.store[d] != 0;
+  // this destination's sources, with the factor each still lacks (0: nothing to add)
+  const T* src[2 * kMaxPairs];
   T scale[2 * kMaxPairs];
+  bool aligned = (reinterpret_cast<size_t>(dst) & 15) == 0;
 #pragma unroll
   for (int k = 0; k < 2 * kMaxPairs; ++k) {
+    src[k] = nullptr;
     scale[k] = T(0);
-    if (k < ns) {
-      const double* s = cb.sums[d][k];
+    if (k < cb.nsrc && cb.src[k].dst == d) {
+      const double* s = cb.src[k].sums;
       const bool live = !(T(s[5]) * g_photo[0] == T(0) && T(s[6]) * g_geom[0] == T(0));
+      src[k] = cb.src[k].plane;
       scale[k] = live ? pair_scale(s, g_photo, g_geom) : T(0);
+      aligned = aligned && (reinterpret_cast<size_t>(src[k]) & 15) == 0;
     }
   }
   // 16-byte accesses over the part every plane has 16-byte aligned (n is a multiple of Q for every image size
   // in use; the scalar loop below takes whatever is left)
-  bool aligned = (reinterpret_cast<size_t>(dst) & 15) == 0;
-  for (int k = 0; k < ns; ++k) aligned = aligned && (reinterpret_cast<size_t>(cb.src[d][k]) & 15) == 0;
   const size_t nq = aligned ? n / Q : 0;
   for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nq; i += (size_t)gridDim.x * kThreads) {
     Quad<T> acc;
@@ -797,8 +818,8 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
     for (int j = 0; j < Q; ++j) acc.v[j] = T(0);
 #pragma unroll
     for (int k = 0; k < 2 * kMaxPairs; ++k) {
-      if (k < ns && scale[k] != T(0)) {
-        const Quad<T> x = reinterpret_cast<const Quad<T>*>(cb.src[d][k])[i];
+      if (scale[k] != T(0)) {
+        const Quad<T> x = reinterpret_cast<const Quad<T>*>(src[k])[i];
 #pragma unroll
         for (int j = 0; j < Q; ++j) acc.v[j] += scale[k] * x.v[j];
       }
@@ -814,14 +835,23 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
     T acc = T(0);
 #pragma unroll
     for (int k = 0; k < 2 * kMaxPairs; ++k)
-      if (k < ns && scale[k] != T(0)) acc += scale[k] * cb.src[d][k][i];
+      if (scale[k] != T(0)) acc += scale[k] * src[k][i];
     dst[i] = store ? acc : dst[i] + acc;
   }
 }
 
-// Clears the scatter plane of every pair of a batch (before a speculative forward's geometry tail).
+// Before a speculative forward: clears the scatter plane of every pair of a batch and, in its first workgroup,
+// does the work of pairs_prep_kernel (one launch instead of two in front of the dominant kernel).
 template <typename T>
-__global__ __launch_bounds__(kThreads) void pairs_zero_scatter_kernel(PairBatch<T> pb, size_t n) {
+__global__ __launch_bounds__(kThreads) void pairs_zero_prep_kernel(PairBatch<T> pb, size_t n, int npairs, int B,
+                                                                   const T* __restrict__ K) {
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (threadIdx.x == 0) *finalize_counter(pb) = 0u;
+    for (int i = threadIdx.x; i < npairs * B; i += kThreads) {
+      const int pair = i / B, b = i - pair * B;
+      prep_one(b, pb.p[pair].pose, K, pb.p[pair].consts);
+    }
+  }
   T* __restrict__ p = pb.p[blockIdx.y].gbuf + kPlaneScatter * n;
   for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) p[i] = T(0);
 }
@@ -874,13 +904,11 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
   PairBatch<T> pb;
   for (int i = 0; i < n; ++i) pb.p[i] = make_pair_args<T>(d[i], B, H, W, nullptr, i);
   const bool kernel_only = (flags & SCSFM_DEBUG_KERNEL_ONLY) != 0;  // profiling: consts are in place already
-  if (!kernel_only)
-    hipLaunchKernelGGL((pairs_prep_kernel<T>), dim3(ceil_div(n * B, 64)), dim3(64), 0, stream, pb, n, B, K);
   dim3 grid;
   if (spec) {
     const size_t npx = (size_t)B * H * W;
     if (!kernel_only)
-      hipLaunchKernelGGL((pairs_zero_scatter_kernel<T>), dim3(1024, n), dim3(kThreads), 0, stream, pb, npx);
+      hipLaunchKernelGGL((pairs_zero_prep_kernel<T>), dim3(1024, n), dim3(kThreads), 0, stream, pb, npx, n, B, K);
     grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
     const T r_hint = T(3.0 * w_geom / w_photo);
     const bool timed = g_profile.used < g_profile.n;
@@ -894,6 +922,7 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
       hipLaunchKernelGGL((pair_fwd_spec_kernel<T, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags, r_hint);
     if (timed) (void)hipEventRecord(g_profile.stop[g_profile.used++], stream);
   } else {
+    hipLaunchKernelGGL((pairs_prep_kernel<T>), dim3(ceil_div(n * B, 64)), dim3(64), 0, stream, pb, n, B, K);
     grid = dim3(ceil_div(W, kTileW), ceil_div(H, Tile<T>::kH), n * B);
     if (flags & SCSFM_WITH_SSIM)
       hipLaunchKernelGGL((pair_fwd_kernel<T, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags);
@@ -962,34 +991,39 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
       hipLaunchKernelGGL((pair_bwd_geom_kernel<T>), dim3(g), dim3(kThreads), 0, stream, pb, nbx, nby, m * B, B, H, W, flags,
                          g_photo, g_geom);
     }
-    hipLaunchKernelGGL((pairs_pose_reduce_kernel<T>), dim3(m * B), dim3(kWave), 0, stream, pb, B,
-                       nax * nay, nbx * nby, K, g_photo, g_geom);
-    if (!(flags & SCSFM_DEBUG_SKIP_GEOM)) {
+    if (flags & SCSFM_DEBUG_SKIP_GEOM) {
+      hipLaunchKernelGGL((pairs_pose_reduce_kernel<T>), dim3(m * B), dim3(kWave), 0, stream, pb, B, nax * nay, nbx * nby, K,
+                         g_photo, g_geom);
+    } else {
       // group the private planes by the caller's destination buffer: a pair's dense plane belongs to its
       // target depth map, its scatter plane to its reference depth map
       CombineBatch<T> cb;
-      int nd = 0;
+      cb.nd = 0; cb.nsrc = 0;
       for (int i = 0; i < m; ++i) {
         for (int which = 0; which < 2; ++which) {
           T* dst = (T*)(which == 0 ? d[i0 + i].g_tgt_depth : d[i0 + i].g_ref_depth);
           int k = 0;
-          while (k < nd && cb.dst[k] != dst) ++k;
-          if (k == nd) {
-            cb.dst[nd] = dst; cb.nsrc[nd] = 0;
+          while (k < cb.nd && cb.dst[k] != dst) ++k;
+          if (k == cb.nd) {
+            cb.dst[k] = dst;
             int q = 0;
             while (q < nseen && seen[q] != dst) ++q;
-            cb.store[nd] = (!accumulate && q == nseen && nseen < kSeenMax) ? 1 : 0;
+            cb.store[k] = (!accumulate && q == nseen && nseen < kSeenMax) ? 1 : 0;
             if (q == nseen && nseen < kSeenMax) seen[nseen++] = dst;
-            ++nd;
+            ++cb.nd;
           }
-          cb.src[k][cb.nsrc[k]] = pb.p[i].gbuf + (which == 0 ? kPlaneDense : kPlaneScatter) * npx;
-          cb.sums[k][cb.nsrc[k]] = pb.p[i].sums;
-          ++cb.nsrc[k];
+          CombineSrc<T>& sc = cb.src[cb.nsrc++];
+          sc.plane = pb.p[i].gbuf + (which == 0 ? kPlaneDense : kPlaneScatter) * npx;
+          sc.sums = pb.p[i].sums;
+          sc.dst = k;
         }
       }
-      const int gx = (int)((npx + 8 * kThreads - 1) / (8 * kThreads));
-      hipLaunchKernelGGL((pairs_combine_kernel<T>), dim3(gx < 1 ? 1 : gx, nd), dim3(kThreads), 0, stream, cb, npx,
-                         g_photo, g_geom);
+      int gx = (int)((npx + 8 * kThreads - 1) / (8 * kThreads));
+      const int gpose = ceil_div(m * B, kThreads / kWave);
+      gx = gx < gpose ? gpose : gx;
+      // (+ 1 row of workgroups: dL/dpose)
+      hipLaunchKernelGGL((pairs_combine_kernel<T>), dim3(gx, cb.nd + 1), dim3(kThreads), 0, stream, cb, npx, pb, m, B,
+                         nax * nay, nbx * nby, K, g_photo, g_geom);
     }
   }
   return launch_status();
