@@ -334,3 +334,45 @@ def test_speculation_holding_failing_and_absent_agree(dev):
             scale = float(b.abs().max())
             # same arithmetic up to the order of the scatter's atomics and where the scalar factor is applied
             assert float((a - b).abs().max()) <= 2e-4 * scale, (name, scale)
+
+
+@pytest.mark.parametrize("hint,upstream", [((1.0, 0.5), (1.0, 0.5)), ((1.0, 0.5), (0.3, 1.1))])
+def test_no_result_depends_on_uninitialised_memory(dev, monkeypatch, hint, upstream):
+    """Every torch.empty of the wrappers poisoned with NaN bytes: losses identical, gradients equal up to the
+    order of the scatter's atomics (speculation holding, and failing over to the backward's own passes)."""
+    from scsfm_hip import _lib, capi, synth
+    lib = _lib.get()
+    d = synth.make_batch(3, 128, 416, n_ref=2, seed=13, depth="smooth", image="smooth", dataset="kitti")
+    to = lambda t: t.to(dev)
+    tgt, K, refs = to(d["tgt_img"]), to(d["intrinsics"]), [to(t) for t in d["ref_imgs"]]
+    tds, rds = [to(d["tgt_depth"][0])], [[to(r[0])] for r in d["ref_depths"]]
+    ps, pis = [to(p) for p in d["poses"]], [to(p) for p in d["poses_inv"]]
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    gp, gg = torch.full((1,), upstream[0], device=dev), torch.full((1,), upstream[1], device=dev)
+
+    def step():
+        photo, geom, _, ws = capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, hint=hint)
+        g = capi.photo_geometry_bwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, ws, gp, gg)
+        sm, sws = capi.smooth_multi_fwd(lib, tds + [r[0] for r in rds], [tgt] + refs)
+        gs = capi.smooth_multi_bwd(lib, tds + [r[0] for r in rds], [tgt] + refs, sws, torch.ones(1, device=dev))
+        flat = [g[0][0]] + [r[0] for r in g[1]] + list(g[2]) + list(g[3]) + list(gs)
+        return [photo.clone(), geom.clone(), sm.clone()], [t.clone() for t in flat]
+
+    clean_l, clean_g = step()
+    real_empty = torch.empty
+
+    def poisoned(*a, **k):
+        t = real_empty(*a, **k)
+        if t.dtype == torch.uint8:
+            t.fill_(255)
+        elif t.is_floating_point():
+            t.fill_(float("nan"))
+        return t
+
+    monkeypatch.setattr(torch, "empty", poisoned)
+    dirty_l, dirty_g = step()
+    monkeypatch.undo()
+    for a, b in zip(dirty_l, clean_l):
+        assert torch.equal(a, b)
+    for a, b in zip(dirty_g, clean_g):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())

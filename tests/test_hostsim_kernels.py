@@ -348,3 +348,44 @@ def test_more_pair_directions_than_one_launch_holds(lib, hint):
             assert _rel(g_rd[i][s], rd[i][s].grad) < 1e-10
     for i in range(3):
         assert _rel(g_p[i], pp[i].grad) < 1e-10 and _rel(g_pi[i], pi[i].grad) < 1e-10
+
+
+@pytest.mark.parametrize("hint,upstream", [((1.0, 0.5), (1.0, 0.5)), ((1.0, 0.5), (0.3, 1.1)), (None, (1.0, 0.5))])
+def test_no_result_depends_on_uninitialised_memory(lib, monkeypatch, hint, upstream):
+    """Workspaces, scratch planes, loss rows and gradient buffers come from torch.empty.  With every such
+    allocation poisoned (all-ones bytes = NaN) the step must give exactly what it gives on clean memory:
+    everything that is read was written first, and the batched backwards store rather than accumulate."""
+    d = synth.make_batch(2, 72, 100, n_ref=2, seed=31, depth="smooth")
+    c = lambda x: x.double().contiguous()
+    ti, K = c(d["tgt_img"]), c(d["intrinsics"])
+    ris = [c(r) for r in d["ref_imgs"]]
+    tds, rds = [c(d["tgt_depth"][0])], [[c(r[0])] for r in d["ref_depths"]]
+    ps, pis = [c(p) for p in d["poses"]], [c(p) for p in d["poses_inv"]]
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    gp = torch.tensor([upstream[0]], dtype=torch.float64)
+    gg = torch.tensor([upstream[1]], dtype=torch.float64)
+
+    def step():
+        photo, geom, _, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=hint)
+        g = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, gp, gg)
+        sm, sws = capi.smooth_multi_fwd(lib, tds + [r[0] for r in rds], [ti] + ris)
+        gs = capi.smooth_multi_bwd(lib, tds + [r[0] for r in rds], [ti] + ris, sws, torch.ones(1, dtype=torch.float64))
+        flat = [g[0][0]] + [r[0] for r in g[1]] + list(g[2]) + list(g[3]) + list(gs)
+        return [photo.clone(), geom.clone(), sm.clone()] + [t.clone() for t in flat]
+
+    clean = step()
+    real_empty = torch.empty
+
+    def poisoned(*a, **k):
+        t = real_empty(*a, **k)
+        if t.dtype == torch.uint8:
+            t.fill_(255)
+        elif t.is_floating_point():
+            t.fill_(float("nan"))
+        return t
+
+    monkeypatch.setattr(torch, "empty", poisoned)
+    dirty = step()
+    monkeypatch.undo()
+    for a, b in zip(dirty, clean):
+        assert torch.equal(a, b)
