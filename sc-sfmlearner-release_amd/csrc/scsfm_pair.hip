@@ -754,7 +754,7 @@ __global__ void pairs_pose_reduce_kernel(PairBatch<T> pb, int B, int nblk_spec, 
 
 // dst[d] (+)= sum_k scale_k * src_k: the dense planes of the pairs whose target depth map dst is and the scatter
 // planes of the pairs that sampled it.  A pair whose passes skipped (both upstream coefficients zero) left its
-// planes untouched and is skipped here too.  The last row of workgroups (blockIdx.y == nd) does what
+// planes untouched and is skipped here too.  The first row of workgroups (blockIdx.y == 0) does what
 // pairs_pose_reduce_kernel does, one wave per (pair, batch element): dL/dpose rides along for free.
 template <typename T>
 struct CombineSrc {
@@ -778,8 +778,10 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
                                                                  int B, int nblk_spec, int nblk_geom,
                                                                  const T* __restrict__ K, const T* __restrict__ g_photo,
                                                                  const T* __restrict__ g_geom) {
-  const int d = blockIdx.y;
-  if (d == cb.nd) {  // the pose row
+  // row 0 of the grid is dispatched first: the pose waves (one latency-bound reduction each) start at once and
+  // finish under the streaming rows instead of after them
+  const int d = (int)blockIdx.y - 1;
+  if (d < 0) {  // the pose row
     const int item = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
     if (item < npairs * B) {
       const int pair = item / B, b = item - pair * B;
