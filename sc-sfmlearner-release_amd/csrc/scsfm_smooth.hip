@@ -16,7 +16,10 @@
 
 namespace scsfm {
 
-constexpr int kSmRows = 4;  // rows per thread
+#ifndef SCSFM_SMOOTH_ROWS  // tuning knob (tools/build_variants.sh)
+#define SCSFM_SMOOTH_ROWS 4
+#endif
+constexpr int kSmRows = SCSFM_SMOOTH_ROWS;  // rows per thread
 constexpr int kMaxFrames = 8;
 
 struct SmoothWs {
