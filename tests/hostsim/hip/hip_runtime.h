@@ -152,9 +152,15 @@ inline void run_block(const std::function<void()>& body) {
   }
   int remaining = n;
   long spins = 0;
+  // HOSTSIM_ORDER=reverse runs the threads of a block (and, in launch(), the blocks of a grid) in descending
+  // order: a result that depends on the order in which threads run between two barriers is a data race
+  // (tests/test_hostsim_kernels.py runs the fused kernels under both orders).
+  const char* order = getenv("HOSTSIM_ORDER");
+  const bool reverse = order && order[0] == 'r';
   while (remaining > 0) {
     int progressed = 0;
-    for (int t = 0; t < n; ++t) {
+    for (int k = 0; k < n; ++k) {
+      const int t = reverse ? n - 1 - k : k;
       Fiber& f = s.fibers[t];
       if (f.done) continue;
       set_thread(t);
@@ -182,12 +188,14 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   }
   bdim() = {block.x, block.y, block.z};
   gdim() = {grid.x, grid.y, grid.z};
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
-        bidx() = {bx, by, bz};
-        run_block(body);
-      }
+  const char* order = getenv("HOSTSIM_ORDER");
+  const bool reverse = order && order[0] == 'r';
+  const unsigned long nb = (unsigned long)grid.x * grid.y * grid.z;
+  for (unsigned long k = 0; k < nb; ++k) {
+    const unsigned long l = reverse ? nb - 1 - k : k;
+    bidx() = {(unsigned)(l % grid.x), (unsigned)((l / grid.x) % grid.y), (unsigned)(l / ((unsigned long)grid.x * grid.y))};
+    run_block(body);
+  }
 }
 }  // namespace hostsim
 

@@ -389,3 +389,13 @@ def test_no_result_depends_on_uninitialised_memory(lib, monkeypatch, hint, upstr
     monkeypatch.undo()
     for a, b in zip(dirty, clean):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("hint,upstream", [((0.7, 1.3), (0.7, 1.3)), ((0.7, 1.3), (1.0, 0.5)), (None, (0.7, 1.3))])
+def test_thread_and_block_order_do_not_matter(lib, monkeypatch, hint, upstream):
+    """HOSTSIM_ORDER=reverse runs the threads of every workgroup, and the workgroups of every grid, in
+    descending order.  The fused kernels (LDS tiles re-used for parking, window, reduction scratch) must still
+    reproduce the oracle: a dependence on the order in which threads run between two barriers is a data race."""
+    monkeypatch.setenv("HOSTSIM_ORDER", "reverse")
+    test_speculative_forward_fp64(lib, hint, upstream)
+    test_smooth_matches_oracle_and_golden(lib)
