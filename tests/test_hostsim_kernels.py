@@ -399,3 +399,29 @@ def test_thread_and_block_order_do_not_matter(lib, monkeypatch, hint, upstream):
     monkeypatch.setenv("HOSTSIM_ORDER", "reverse")
     test_speculative_forward_fp64(lib, hint, upstream)
     test_smooth_matches_oracle_and_golden(lib)
+
+
+@pytest.mark.parametrize("H,W,B", [(15, 63, 40), (33, 129, 8), (5, 200, 40)])
+@pytest.mark.parametrize("hint", [(1.0, 0.5), None])
+def test_odd_image_sizes_with_open_gates(lib, H, W, B, hint):
+    """Sizes that are no multiple of any tile (a last partial tile in both directions, images narrower than a
+    wave or lower than a strip), with enough pixels in the batch that the 10000-pixel gates are open, against
+    the fp64 oracle: the fused forward + combine, and the plain forward + the backward's two passes."""
+    d = synth.make_batch(B, H, W, n_ref=1, seed=H * 100 + W, depth="smooth")
+    c = lambda x: x.double().contiguous()
+    ti, K = c(d["tgt_img"]), c(d["intrinsics"])
+    ris = [c(r) for r in d["ref_imgs"]]
+    tds, rds = [c(d["tgt_depth"][0])], [[c(r[0])] for r in d["ref_depths"]]
+    ps, pis = [c(p) for p in d["poses"]], [c(p) for p in d["poses_inv"]]
+    td, rd = [leaf(t) for t in tds], [[leaf(t) for t in r] for r in rds]
+    pp, pi = [leaf(p) for p in ps], [leaf(p) for p in pis]
+    po, go = O.photo_and_geometry_loss(ti, ris, K, td, rd, pp, pi, 1, 1, 1, 1, "zeros")
+    assert float(po) > 0 and float(go) > 0  # gates open
+    (1.0 * po + 0.5 * go).backward()
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    photo, geom, _, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=hint)
+    assert abs(float(photo) - float(po)) < 1e-12 and abs(float(geom) - float(go)) < 1e-12
+    one, half = torch.tensor([1.0], dtype=torch.float64), torch.tensor([0.5], dtype=torch.float64)
+    g_td, g_rd, g_p, g_pi = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, one, half)
+    assert _rel(g_td[0], td[0].grad) < 1e-10 and _rel(g_rd[0][0], rd[0][0].grad) < 1e-10
+    assert _rel(g_p[0], pp[0].grad) < 1e-10 and _rel(g_pi[0], pi[0].grad) < 1e-10
