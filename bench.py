@@ -73,6 +73,17 @@ def hot_path_step(LF, x, flags):
     return loss, photo, smooth, geom
 
 
+def hot_path_step_single_node(LF, x, flags):
+    """The same step through this repo's extension compute_total_loss: both losses and the weighted sum behind
+    one autograd node (not the reference's call structure, hence not the headline)."""
+    for t in x["tgt_depth"] + [t for r in x["ref_depths"] for t in r] + x["poses"] + x["poses_inv"]:
+        t.grad = None
+    loss, photo, smooth, geom = LF.compute_total_loss(x["tgt_img"], x["ref_imgs"], x["K"], x["tgt_depth"], x["ref_depths"],
+                                                      x["poses"], x["poses_inv"], 1, *flags, W_PHOTO, W_SMOOTH, W_GEOM)
+    loss.backward()
+    return loss, photo, smooth, geom
+
+
 def pmc_traffic(args, n_pairs):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_latest.json:
     FETCH_SIZE + WRITE_SIZE in KiB per dispatch, collected in separate `rocprofv3 --pmc` runs of this very
@@ -319,6 +330,18 @@ def main():
     import gc
     gc.collect()
     elapsed, launch = eager_elapsed, "eager launches from Python"
+    # extension leg, eager: the step behind ONE autograd node (compute_total_loss).  Measured before any graph is
+    # captured: a live capture keeps stream-bound autograd nodes alive and slows later eager steps down.
+    single = None
+    try:
+        se, so = timed(lambda: hot_path_step_single_node(LF, x, flags))
+        svals = [float(v.detach()) for v in so]
+        del so
+        gc.collect()
+        single = {"eager_ms_per_step": round(se / args.steps * 1e3, 4),
+                  "losses_match": all(abs(a - b) <= 1e-6 * max(1.0, abs(b)) for a, b in zip(svals, eager_vals))}
+    except Exception as exc:
+        single = {"error": f"{type(exc).__name__}: {exc}"}
     graph_err = None
     if args.graph and (world == 1 or args.graph > 1):
         # the same step captured once into a HIP graph and replayed: identical kernels and results, one launch
@@ -337,6 +360,18 @@ def main():
     else:
         gvals = eager_vals
     loss, photo, smooth, geom = gvals
+
+    # extension leg as a graph replay
+    if single is not None and "error" not in single and args.graph and (world == 1 or args.graph > 1):
+        try:
+            from scsfm_hip.graphs import GraphedStep
+            gs1 = GraphedStep(lambda: hot_path_step_single_node(LF, x, flags))
+            sg, _ = timed(gs1.replay)
+            single["ms_per_step"] = round(sg / args.steps * 1e3, 4)
+        except Exception as exc:
+            single["graph_error"] = f"{type(exc).__name__}: {exc}"
+    gs = gs1 = None  # drop the captures (and the autograd graphs their outputs hold) before the remaining legs
+    gc.collect()
 
     n_px = args.batch * args.height * args.width
     ms_per_step = elapsed / args.steps * 1e3
@@ -389,6 +424,7 @@ def main():
             "warp_loss_ms_per_step": round(ms_per_step, 4),
             "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
             "graph_error": graph_err,
+            "single_autograd_node": single,
             "step_algorithmic_GBs": round(step_bytes(n_px, args.n_ref) / (elapsed / args.steps) / 1e9, 1),
             "step_frac_of_hbm_peak": round(step_bytes(n_px, args.n_ref) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "kernel_us": {k: round(v * 1e6, 2) for k, v in kt.items()},

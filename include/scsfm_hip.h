@@ -55,7 +55,8 @@ extern "C" {
 #define SCSFM_ERR_ARG (-1)
 
 /* ABI version of this header; bumped on any change of a signature or of what an entry point does with its
- * buffers (2: the batched backwards store their depth gradients; scratch holds six planes). */
+ * buffers (2: the batched backwards store their depth gradients; scratch holds six planes.  3: scsfm_smooth_multi_bwd
+ * takes `accumulate`; scsfm_step_total / scsfm_step_weights; scsfm_pair_desc::total). */
 int scsfm_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -247,7 +248,8 @@ int scsfm_masked_mean_bwd_f64(int B, int C, int Cm, int HW, const double* mask, 
 /* compute_smooth_loss (loss_functions.py:154-159): n frames per call.  depths / imgs / g_depths / edges
  * are HOST arrays of n DEVICE pointers; ws = n * scsfm_smooth_ws_bytes(B,H,W) bytes; out[n + 1] (device,
  * store) holds one loss per frame and, in out[n], their sum (what compute_smooth_loss returns); g_depths[i] is STORED (every pixel is written, no zero-fill needed;
- * the single-frame scsfm_smooth_bwd accumulates); a NULL g_depths[i] skips that frame's gradient.
+ * the single-frame scsfm_smooth_bwd accumulates) unless `accumulate` is non-zero; a NULL g_depths[i] skips
+ * that frame's gradient.
  * edges (may be NULL, as may any entry): per frame a [B,H,W] plane in which the forward leaves each
  * pixel's summed edge terms; given the same plane, the backward is a pure stream (4 B read + 4 B
  * written per pixel) instead of re-evaluating the edge weights from the images. */
@@ -255,12 +257,27 @@ int scsfm_smooth_multi_fwd_f32(int n, const void* const* depths, const void* con
                                int W, void* ws, void* const* edges, float* out, void* stream);
 int scsfm_smooth_multi_bwd_f32(int n, const void* const* depths, const void* const* imgs, int B, int H,
                                int W, void* ws, void* const* edges, const float* g_loss,
-                               void* const* g_depths, void* stream);
+                               void* const* g_depths, int accumulate, void* stream);
 int scsfm_smooth_multi_fwd_f64(int n, const void* const* depths, const void* const* imgs, int B, int H,
                                int W, void* ws, void* const* edges, double* out, void* stream);
 int scsfm_smooth_multi_bwd_f64(int n, const void* const* depths, const void* const* imgs, int B, int H,
                                int W, void* ws, void* const* edges, const double* g_loss,
-                               void* const* g_depths, void* stream);
+                               void* const* g_depths, int accumulate, void* stream);
+
+/* The weighted sum of a training step, loss = w_photo * photo + w_smooth * smooth + w_geom * geometry
+ * (train.py:268), for callers that keep the three losses behind ONE autograd node:
+ * scsfm_step_total  : photo_geom[2] = {photo, geometry} (the `total` of scsfm_pairs_fwd), smooth[1] (out[n] of
+ *                     scsfm_smooth_multi_fwd) -> out[4] = {loss, photo, smooth, geometry} (device, store).
+ * scsfm_step_weights: g_loss[1] -> out[3] = {w_photo g, w_geom g, w_smooth g}: the upstream gradients to hand
+ *                     to scsfm_pairs_bwd (out, out + 1) and scsfm_smooth_multi_bwd (out + 2). */
+int scsfm_step_total_f32(const float* photo_geom, const float* smooth, double w_photo, double w_smooth,
+                         double w_geom, float* out, void* stream);
+int scsfm_step_total_f64(const double* photo_geom, const double* smooth, double w_photo, double w_smooth,
+                         double w_geom, double* out, void* stream);
+int scsfm_step_weights_f32(const float* g_loss, double w_photo, double w_smooth, double w_geom, float* out,
+                           void* stream);
+int scsfm_step_weights_f64(const double* g_loss, double w_photo, double w_smooth, double w_geom, double* out,
+                           void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The training input transform on the device (train.py:95-100; custom_transforms.py:33-84):

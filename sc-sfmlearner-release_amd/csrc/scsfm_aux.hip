@@ -182,6 +182,37 @@ static int masked_mean_bwd(int B, int C, int Cm, int HW, const T* mask, void* ws
   return launch_status();
 }
 
+// loss = w1 * photo + w2 * smooth + w3 * geometry (train.py:268) and, for the backward, the three upstream
+// gradients {w1 g, w3 g, w2 g} of the photometric, geometry and smooth terms: one single-thread launch each
+// instead of five / three elementwise launches.
+template <typename T>
+__global__ void step_total_kernel(const T* __restrict__ pg, const T* __restrict__ sm, T w1, T w2, T w3,
+                                  T* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const T photo = pg[0], geom = pg[1], smooth = sm[0];
+    out[0] = w1 * photo + w2 * smooth + w3 * geom;
+    out[1] = photo; out[2] = smooth; out[3] = geom;
+  }
+}
+template <typename T>
+__global__ void step_weights_kernel(const T* __restrict__ g, T w1, T w2, T w3, T* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = w1 * g[0]; out[1] = w3 * g[0]; out[2] = w2 * g[0]; }
+}
+template <typename T>
+static int step_total(const T* pg, const T* sm, double w1, double w2, double w3, T* out, void* stream) {
+  clear_status();
+  if (!pg || !sm || !out) return SCSFM_ERR_ARG;
+  hipLaunchKernelGGL((step_total_kernel<T>), dim3(1), dim3(kWave), 0, (hipStream_t)stream, pg, sm, T(w1), T(w2), T(w3), out);
+  return launch_status();
+}
+template <typename T>
+static int step_weights(const T* g, double w1, double w2, double w3, T* out, void* stream) {
+  clear_status();
+  if (!g || !out) return SCSFM_ERR_ARG;
+  hipLaunchKernelGGL((step_weights_kernel<T>), dim3(1), dim3(kWave), 0, (hipStream_t)stream, g, T(w1), T(w2), T(w3), out);
+  return launch_status();
+}
+
 }  // namespace scsfm
 
 extern "C" {
@@ -203,6 +234,14 @@ size_t scsfm_masked_mean_ws_bytes(void) { return (4 + 2 * (size_t)scsfm::kMmBloc
   int scsfm_masked_mean_bwd_##SUF(int B, int C, int Cm, int HW, const T* mask, void* ws, const T* g, T* g_diff,       \
                                   void* stream) {                                                                     \
     return scsfm::masked_mean_bwd<T>(B, C, Cm, HW, mask, ws, g, g_diff, stream);                                      \
+  }                                                                                                                   \
+  int scsfm_step_total_##SUF(const T* photo_geom, const T* smooth, double w_photo, double w_smooth, double w_geom,    \
+                             T* out, void* stream) {                                                                  \
+    return scsfm::step_total<T>(photo_geom, smooth, w_photo, w_smooth, w_geom, out, stream);                          \
+  }                                                                                                                   \
+  int scsfm_step_weights_##SUF(const T* g_loss, double w_photo, double w_smooth, double w_geom, T* out,               \
+                               void* stream) {                                                                        \
+    return scsfm::step_weights<T>(g_loss, w_photo, w_smooth, w_geom, out, stream);                                    \
   }
 
 SCSFM_AUX_API(f32, float)

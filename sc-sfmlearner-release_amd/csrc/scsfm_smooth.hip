@@ -329,8 +329,9 @@ size_t scsfm_smooth_ws_bytes(int B, int H, int W) {
   }                                                                                                                  \
   int scsfm_smooth_multi_bwd_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,   \
                                    void* ws, void* const* edges, const T* g_loss, void* const* g_depths,             \
-                                   void* stream) {                                                                   \
-    return scsfm::smooth_multi_bwd<T>(n, depths, imgs, B, H, W, ws, edges, g_loss, g_depths, false, stream);         \
+                                   int accumulate, void* stream) {                                                   \
+    return scsfm::smooth_multi_bwd<T>(n, depths, imgs, B, H, W, ws, edges, g_loss, g_depths, accumulate != 0,        \
+                                      stream);                                                                       \
   }                                                                                                                  \
   int scsfm_smooth_fwd_##SUF(int B, int H, int W, const T* depth, const T* img, void* ws, T* out, void* stream) {    \
     const void* d = depth; const void* im = img;                                                                     \

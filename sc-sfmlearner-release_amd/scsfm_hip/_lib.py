@@ -66,7 +66,7 @@ class CLib:
             fn.restype = ret
             fn.argtypes = argtypes
             self._fn[name] = fn
-        if self._dll.scsfm_abi_version() != 2:
+        if self._dll.scsfm_abi_version() != 3:
             raise ScsfmError(f"{path}: ABI version mismatch")
 
     def call(self, name, *args):

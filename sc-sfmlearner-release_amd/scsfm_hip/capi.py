@@ -391,17 +391,37 @@ def smooth_multi_fwd(lib, depths, imgs, keep_edges=True):
     return outs[n], ws
 
 
-def smooth_multi_bwd(lib, depths, imgs, ws, g_loss, need=None):
-    """-> list of dL/d depth (None where ``need[i]`` is False)."""
+def smooth_multi_bwd(lib, depths, imgs, ws, g_loss, need=None, into=None):
+    """-> list of dL/d depth (None where ``need[i]`` is False).  ``into``: existing gradient buffers (one per
+    frame) that the smooth gradient is ADDED to instead of being stored into fresh ones."""
     B, _, H, W = imgs[0].shape
     n = len(depths)
     ws_bytes = _sizes(lib, B, H, W)[2]
     plane_bytes = ((B * H * W * imgs[0].element_size() + 255) // 256) * 256
     has_edges = ws.numel() == n * (ws_bytes + plane_bytes)
     edges = (_ct.c_void_p * n)(*[ws.data_ptr() + n * ws_bytes + i * plane_bytes for i in range(n)]) if has_edges else None
-    # the library stores every pixel of a wanted gradient: no zero-fill
-    g_all = torch.empty((n,) + tuple(depths[0].shape), dtype=depths[0].dtype, device=depths[0].device)
-    grads = [g_all[i] if (need is None or need[i]) else None for i in range(n)]
+    if into is not None:
+        grads = [into[i] if (need is None or need[i]) else None for i in range(n)]
+    else:
+        # the library stores every pixel of a wanted gradient: no zero-fill
+        g_all = torch.empty((n,) + tuple(depths[0].shape), dtype=depths[0].dtype, device=depths[0].device)
+        grads = [g_all[i] if (need is None or need[i]) else None for i in range(n)]
     lib.call(f"scsfm_smooth_multi_bwd_{_suffix(imgs[0])}", n, _ptr_array(depths), _ptr_array(imgs), B, H, W, _p(ws),
-             edges, _p(g_loss), _ptr_array(grads), _stream(imgs[0]))
+             edges, _p(g_loss), _ptr_array(grads), 1 if into is not None else 0, _stream(imgs[0]))
     return grads
+
+
+def step_total(lib, photo_geom, smooth, w_photo, w_smooth, w_geom):
+    """-> tensor[4] = {w_photo * photo + w_smooth * smooth + w_geom * geometry, photo, smooth, geometry}."""
+    out = torch.empty(4, dtype=photo_geom.dtype, device=photo_geom.device)
+    lib.call(f"scsfm_step_total_{_suffix(out)}", _p(photo_geom), _p(smooth), float(w_photo), float(w_smooth),
+             float(w_geom), _p(out), _stream(out))
+    return out
+
+
+def step_weights(lib, g_loss, w_photo, w_smooth, w_geom):
+    """-> tensor[3] = {w_photo * g, w_geom * g, w_smooth * g}: the upstream gradients of the three terms."""
+    out = torch.empty(3, dtype=g_loss.dtype, device=g_loss.device)
+    lib.call(f"scsfm_step_weights_{_suffix(out)}", _p(g_loss), float(w_photo), float(w_smooth), float(w_geom), _p(out),
+             _stream(out))
+    return out

@@ -144,6 +144,58 @@ class SmoothLoss(torch.autograd.Function):
         return (None, *grads, *([None] * n))
 
 
+class StepLoss(torch.autograd.Function):
+    """forward(flags, n_ref, n_scales, w_photo, w_smooth, w_geom, tgt_img, K, *ref_imgs, *tgt_depths, *ref_depths,
+    *poses, *poses_inv) -> (loss, photo, smooth, geometry) with loss = w_photo * photo + w_smooth * smooth +
+    w_geom * geometry (train.py:259-268) behind ONE autograd node; photo / smooth / geometry are returned for
+    logging only (not differentiable).
+
+    Compared with the reference's two functions plus the weighted sum this saves what autograd does between
+    them: five scalar kernels forward, three backward, and one elementwise addition per depth map (the smooth
+    gradient is accumulated into the buffers the pair backward just stored).  The speculation hint is the
+    weights themselves, so it always holds when the upstream gradient of the loss is 1."""
+
+    @staticmethod
+    def forward(ctx, flags, n_ref, n_scales, w_photo, w_smooth, w_geom, tgt_img, K, *rest):
+        import numpy as np
+        from . import dist as _dist
+        lib = _lib.get()
+        rest = [_c(t) for t in rest]
+        tgt_img, K = _c(tgt_img), _c(K)
+        _need_cuda(tgt_img, K, *rest)
+        ref_imgs, tgt_depths, ref_depths, poses, poses_inv, _ = PhotoGeometryLoss._split(rest, n_ref, n_scales)
+        hint = (float(np.float32(w_photo)), float(np.float32(w_geom))) if (w_photo != 0 and any(ctx.needs_input_grad)) else None
+        photo, geom, _, ws = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
+                                                     poses_inv, group=_dist.exact_group(), hint=hint)
+        frames = [tgt_depths[0]] + [r[0] for r in ref_depths]
+        imgs = [tgt_img] + list(ref_imgs)
+        smooth, sws = capi.smooth_multi_fwd(lib, frames, imgs, keep_edges=any(ctx.needs_input_grad))
+        # (photo, geom) are elements 0 and 1 of one contiguous row -- the library's totals, or the exact mode's sums
+        assert geom.data_ptr() == photo.data_ptr() + photo.element_size()
+        out = capi.step_total(lib, photo, smooth, w_photo, w_smooth, w_geom)
+        ctx.cfg = (flags, n_ref, n_scales, w_photo, w_smooth, w_geom)
+        ctx.save_for_backward(tgt_img, K, *rest, ws, sws)
+        loss, photo_o, smooth_o, geom_o = out[0], out[1], out[2], out[3]
+        ctx.mark_non_differentiable(photo_o, smooth_o, geom_o)
+        return loss, photo_o, smooth_o, geom_o
+
+    @staticmethod
+    def backward(ctx, g_loss, *_unused):
+        lib = _lib.get()
+        flags, n_ref, n_scales, w_photo, w_smooth, w_geom = ctx.cfg
+        saved = ctx.saved_tensors
+        tgt_img, K = saved[0], saved[1]
+        _no_grad_inputs(ctx, 6, ["tgt_img", "intrinsics"] + [f"ref_imgs[{i}]" for i in range(n_ref)])
+        ref_imgs, tgt_depths, ref_depths, poses, poses_inv, n_in = PhotoGeometryLoss._split(saved[2:], n_ref, n_scales)
+        ws, sws = saved[2 + n_in], saved[3 + n_in]
+        gw = capi.step_weights(lib, _scalar(g_loss, tgt_img), w_photo, w_smooth, w_geom)
+        g_td, g_rd, g_poses, g_poses_inv = capi.photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths,
+                                                                  ref_depths, poses, poses_inv, ws, gw[0:1], gw[1:2])
+        frames = [tgt_depths[0]] + [r[0] for r in ref_depths]
+        capi.smooth_multi_bwd(lib, frames, [tgt_img] + list(ref_imgs), sws, gw[2:3], into=[g_td[0]] + [r[0] for r in g_rd])
+        return (None,) * 6 + (None, None) + (None,) * n_ref + (*g_td, *[g for r in g_rd for g in r], *g_poses, *g_poses_inv)
+
+
 # ------------------------------------------------------------------------------------------------
 # inverse_warp2 as maps, pose_vec2mat
 # ------------------------------------------------------------------------------------------------

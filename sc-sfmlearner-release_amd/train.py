@@ -33,6 +33,10 @@ import custom_transforms
 import models
 from logger import AverageMeter, TermLogger
 from loss_functions import compute_errors, compute_photo_and_geometry_loss, compute_smooth_loss
+try:  # an extension of this repo's loss_functions; absent when the reference's module is on the path
+    from loss_functions import compute_total_loss
+except ImportError:
+    compute_total_loss = None
 from scsfm_hip import config as hip_config
 from scsfm_hip import dist as hip_dist
 from utils import save_checkpoint
@@ -78,6 +82,9 @@ parser.add_argument('--with-gt', action='store_true', help='use ground truth for
 parser.add_argument('--gpu-augment', action='store_true',
                     help='run flip / zoom-crop / normalisation on the GPU (byte-exact with the PIL transform chain) '
                          'instead of in the data-loader workers')
+parser.add_argument('--single-loss-node', type=int, default=1,
+                    help='1: the two losses and their weighted sum behind one autograd node (extension; same values and '
+                         'gradients, fewer launches), 0: the three reference-style calls')
 parser.add_argument('--exact-mask-normalisation', action='store_true',
                     help='data parallel: all-reduce the mask sums so the loss equals the single-process loss on the global batch')
 
@@ -248,11 +255,17 @@ def train_step(args, disp_net, pose_net, optimizer, tgt_img, ref_imgs, intrinsic
     w1, w2, w3 = args.photo_loss_weight, args.smooth_loss_weight, args.geometry_consistency_weight
     tgt_depth, ref_depths = compute_depth(disp_net, tgt_img, ref_imgs)
     poses, poses_inv = compute_pose_with_inv(pose_net, tgt_img, ref_imgs)
-    loss_1, loss_3 = compute_photo_and_geometry_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, poses, poses_inv,
-                                                     args.num_scales, args.with_ssim, args.with_mask, args.with_auto_mask,
-                                                     args.padding_mode)
-    loss_2 = compute_smooth_loss(tgt_depth, tgt_img, ref_depths, ref_imgs)
-    loss = w1 * loss_1 + w2 * loss_2 + w3 * loss_3
+    if getattr(args, 'single_loss_node', 1) and compute_total_loss is not None:
+        # the three lines of the reference below as one autograd node (same values and gradients, fewer launches)
+        loss, loss_1, loss_2, loss_3 = compute_total_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, poses,
+                                                          poses_inv, args.num_scales, args.with_ssim, args.with_mask,
+                                                          args.with_auto_mask, args.padding_mode, w1, w2, w3)
+    else:  # train.py:259-268 verbatim
+        loss_1, loss_3 = compute_photo_and_geometry_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, poses,
+                                                         poses_inv, args.num_scales, args.with_ssim, args.with_mask,
+                                                         args.with_auto_mask, args.padding_mode)
+        loss_2 = compute_smooth_loss(tgt_depth, tgt_img, ref_depths, ref_imgs)
+        loss = w1 * loss_1 + w2 * loss_2 + w3 * loss_3
     optimizer.zero_grad(set_to_none=True)
     # exact mode: every rank holds the GLOBAL loss and DDP averages gradients -> scale by the world size
     scale = getattr(args, 'world', 1) if getattr(args, 'exact_mask_normalisation', False) else 1

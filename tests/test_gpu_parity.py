@@ -376,3 +376,31 @@ def test_no_result_depends_on_uninitialised_memory(dev, monkeypatch, hint, upstr
         assert torch.equal(a, b)
     for a, b in zip(dirty_g, clean_g):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+def test_single_node_step_equals_the_three_reference_style_calls(LF, dev):
+    """compute_total_loss (extension: one autograd node for both losses and the weighted sum) against the
+    reference's call structure on the device, values and gradients."""
+    from scsfm_hip import synth
+    d = synth.make_batch(4, 128, 416, n_ref=2, seed=17, depth="smooth", image="smooth", dataset="kitti")
+    to = lambda t: t.to(dev)
+    tgt, K, refs = to(d["tgt_img"]), to(d["intrinsics"]), [to(t) for t in d["ref_imgs"]]
+    w1, w2, w3 = 1.0, 0.1, 0.5
+
+    def leaves():
+        mk = lambda t: to(t).clone().requires_grad_(True)
+        return ([mk(t) for t in d["tgt_depth"]], [[mk(t) for t in r] for r in d["ref_depths"]],
+                [mk(p) for p in d["poses"]], [mk(p) for p in d["poses_inv"]])
+
+    td, rd, pp, pi = leaves()
+    photo, geom = LF.compute_photo_and_geometry_loss(tgt, refs, K, td, rd, pp, pi, 1, 1, 1, 1, "zeros")
+    smooth = LF.compute_smooth_loss(td, tgt, rd, refs)
+    (w1 * photo + w2 * smooth + w3 * geom).backward()
+    td2, rd2, pp2, pi2 = leaves()
+    loss, l1, l2, l3 = LF.compute_total_loss(tgt, refs, K, td2, rd2, pp2, pi2, 1, 1, 1, 1, "zeros", w1, w2, w3)
+    loss.backward()
+    assert float(l1) == float(photo) and float(l2) == float(smooth) and float(l3) == float(geom)
+    assert abs(float(loss) - float(w1 * photo + w2 * smooth + w3 * geom)) <= 1e-6
+    for a, b in zip(td + [t for r in rd for t in r] + pp + pi, td2 + [t for r in rd2 for t in r] + pp2 + pi2):
+        scale = float(a.grad.abs().max())
+        assert float((b.grad - a.grad).abs().max()) <= 2e-5 * scale

@@ -425,3 +425,38 @@ def test_odd_image_sizes_with_open_gates(lib, H, W, B, hint):
     g_td, g_rd, g_p, g_pi = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, one, half)
     assert _rel(g_td[0], td[0].grad) < 1e-10 and _rel(g_rd[0][0], rd[0][0].grad) < 1e-10
     assert _rel(g_p[0], pp[0].grad) < 1e-10 and _rel(g_pi[0], pi[0].grad) < 1e-10
+
+
+@pytest.mark.parametrize("n_scales", [1, 2])
+def test_single_node_step_equals_the_three_reference_style_calls(lib, monkeypatch, n_scales):
+    """compute_total_loss (one autograd node: both losses + the weighted sum) against
+    compute_photo_and_geometry_loss + compute_smooth_loss + w1*l1 + w2*l2 + w3*l3, values and gradients, fp64,
+    through the autograd nodes with the host-simulation library."""
+    import loss_functions as LF
+    from scsfm_hip import _lib, ops
+    monkeypatch.setattr(_lib, "get", lambda: lib)
+    monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)
+    H, W = 72, 100
+    d = synth.make_batch(2, H, W, n_ref=2, seed=41, depth="smooth", num_scales=n_scales)
+    c = lambda x: x.double().contiguous()
+    ti, K = c(d["tgt_img"]), c(d["intrinsics"])
+    ris = [c(r) for r in d["ref_imgs"]]
+    w1, w2, w3 = 1.0, 0.1, 0.5
+
+    def leaves():
+        return ([leaf(c(t)) for t in d["tgt_depth"]], [[leaf(c(t)) for t in r] for r in d["ref_depths"]],
+                [leaf(c(p)) for p in d["poses"]], [leaf(c(p)) for p in d["poses_inv"]])
+
+    td, rd, pp, pi = leaves()
+    photo, geom = LF.compute_photo_and_geometry_loss(ti, ris, K, td, rd, pp, pi, n_scales, 1, 1, 1, "zeros")
+    smooth = LF.compute_smooth_loss(td, ti, rd, ris)
+    (w1 * photo + w2 * smooth + w3 * geom).backward()
+    td2, rd2, pp2, pi2 = leaves()
+    loss, l1, l2, l3 = LF.compute_total_loss(ti, ris, K, td2, rd2, pp2, pi2, n_scales, 1, 1, 1, "zeros", w1, w2, w3)
+    assert not l1.requires_grad and not l2.requires_grad and not l3.requires_grad
+    loss.backward()
+    assert abs(float(l1) - float(photo)) < 1e-14 and abs(float(l2) - float(smooth)) < 1e-14
+    assert abs(float(l3) - float(geom)) < 1e-14
+    assert abs(float(loss) - float(w1 * photo + w2 * smooth + w3 * geom)) < 1e-13
+    for a, b in zip(td + [t for r in rd for t in r] + pp + pi, td2 + [t for r in rd2 for t in r] + pp2 + pi2):
+        assert _rel(b.grad, a.grad) < 1e-11

@@ -27,11 +27,14 @@ def main():
     ap.add_argument("--dataset", default="kitti")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--single", action="store_true", help="the single-autograd-node step (compute_total_loss)")
     a = ap.parse_args()
     import loss_functions as LF
     dev = torch.device("cuda:0")
     x, _ = bench.make_inputs(a, 0, dev)
     flags = (1, 1, 1, "zeros")
+    if a.single:
+        bench.hot_path_step = bench.hot_path_step_single_node
     for _ in range(20):
         bench.hot_path_step(LF, x, flags)
     torch.cuda.synchronize()
