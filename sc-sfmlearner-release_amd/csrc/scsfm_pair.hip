@@ -739,6 +739,19 @@ __device__ __forceinline__ T pair_scale(const double* __restrict__ sums, const T
   return spec_valid(sums, g_photo, g_geom) ? T(sums[5]) * g_photo[0] : T(1);
 }
 
+// After a backward whose upstream gradients did NOT stand in the hinted ratio, passes A and B have overwritten the
+// speculative planes and pose partials with fully scaled values: the workspace no longer holds a speculative
+// forward.  Clearing the flag makes any later backward on the same workspace (retain_graph=True) recompute with
+// its own coefficients instead of rescaling those planes once more.  The flag only ever goes 1 -> 0 while
+// spec_valid() is already false, so the other workgroups of the launch that evaluate spec_valid() concurrently
+// see the same answer either way.  (A backward with both coefficients zero ran no pass and leaves it alone.)
+template <typename T>
+__device__ __forceinline__ void retire_speculation(double* __restrict__ sums, const T* __restrict__ g_photo,
+                                                   const T* __restrict__ g_geom) {
+  const bool zero = T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0);
+  if (sums[8] != 0.0 && !zero && !spec_valid(sums, g_photo, g_geom)) sums[8] = 0.0;
+}
+
 // One wave per (pair, batch element): reduce the per-block partials of dL/d(A|c), finish dL/dpose.
 // nblk_spec / nblk_geom: blocks per image of the kernel that wrote them (geometry tail of the speculative
 // forward, or the geometry pass).
@@ -750,6 +763,7 @@ __global__ void pairs_pose_reduce_kernel(PairBatch<T> pb, int B, int nblk_spec, 
   const bool spec = spec_valid(pa.sums, g_photo, g_geom);
   pose_reduce_one(b, spec ? nblk_spec : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K, pa.gPp,
                   pa.sums, g_photo, g_geom, pa.g_pose);
+  if (b == 0 && threadIdx.x == 0) retire_speculation(pa.sums, g_photo, g_geom);
 }
 
 // dst[d] (+)= sum_k scale_k * src_k: the dense planes of the pairs whose target depth map dst is and the scatter
@@ -789,6 +803,7 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
       const bool spec = spec_valid(pa.sums, g_photo, g_geom);
       pose_reduce_one(b, spec ? nblk_spec : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K, pa.gPp,
                       pa.sums, g_photo, g_geom, pa.g_pose);
+      if (b == 0 && (threadIdx.x & (kWave - 1)) == 0) retire_speculation(pa.sums, g_photo, g_geom);
     }
     return;
   }

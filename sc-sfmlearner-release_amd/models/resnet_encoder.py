@@ -93,6 +93,16 @@ class ResNet(nn.Module):
 _CFG = {18: (BasicBlock, [2, 2, 2, 2]), 50: (Bottleneck, [3, 4, 6, 3])}
 
 
+def imagenet_weights_path(num_layers):
+    """Local stand-in for the reference's model-zoo download: $SCSFM_IMAGENET_WEIGHTS/resnet<N>.pth or None."""
+    import os
+    root = os.environ.get("SCSFM_IMAGENET_WEIGHTS")
+    if not root:
+        return None
+    path = os.path.join(root, "resnet{}.pth".format(num_layers))
+    return path if os.path.exists(path) else None
+
+
 class ResnetEncoder(nn.Module):
     """Five feature maps at strides 2..32 (models/resnet_encoder.py:64-97)."""
 
@@ -100,15 +110,23 @@ class ResnetEncoder(nn.Module):
         super().__init__()
         if num_layers not in _CFG:
             raise ValueError("{} is not a valid number of resnet layers".format(num_layers))
-        if pretrained:
-            # the reference downloads ImageNet weights (models/resnet_encoder.py:53-59); there is no
-            # network here -- load a checkpoint with --pretrained-disp / --pretrained-pose instead
-            raise RuntimeError("ImageNet-pretrained weights are not reachable offline: use --with-pretrain 0")
         block, layers = _CFG[num_layers]
         self.num_ch_enc = np.array([64, 64, 128, 256, 512])
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
         self.encoder = ResNet(block, layers, num_input_images=num_input_images)
+        if pretrained:
+            # the reference downloads ImageNet weights (models/resnet_encoder.py:53-59); offline they come from a
+            # local torchvision state dict: $SCSFM_IMAGENET_WEIGHTS/resnet<N>.pth (train.py checks this at
+            # argument-parsing time, before any dataset is touched)
+            path = imagenet_weights_path(num_layers)
+            if path is None:
+                raise RuntimeError("ImageNet-pretrained weights are not reachable offline: set SCSFM_IMAGENET_WEIGHTS "
+                                   "to a directory holding resnet{}.pth, or use --with-pretrain 0".format(num_layers))
+            loaded = torch.load(path, map_location="cpu")
+            # several stacked input frames: the first convolution's filters repeated and rescaled (:55-57)
+            loaded['conv1.weight'] = torch.cat([loaded['conv1.weight']] * num_input_images, 1) / num_input_images
+            self.encoder.load_state_dict(loaded)
         # never reached by forward(): frozen so that DistributedDataParallel does not wait for them
         for p in self.encoder.fc.parameters():
             p.requires_grad_(False)

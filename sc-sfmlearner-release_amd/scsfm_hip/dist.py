@@ -7,9 +7,12 @@ reference itself runs the whole loss on GPU 0, train.py:168-169).  The optional 
 reproduces the reference's whole-batch semantics (the masked means are ratios of global sums and
 the 10000-pixel gate is on the global count, loss_functions.py:123-129): one tiny all-reduce of
 the [n_pairs, 3] raw sums between the forward reduction and the backward kernels.  In that mode
-every rank returns the GLOBAL loss; multiply it by the world size before ``backward()`` if the
-parameter gradients are subsequently *averaged* (DistributedDataParallel) so that the averaged
-gradient equals the single-process gradient.
+every rank returns the GLOBAL photo / geometry losses with gradients w.r.t. its own shard; if the
+parameter gradients are subsequently *averaged* (DistributedDataParallel), multiply THOSE TWO terms
+by the world size before ``backward()`` so that the averaged gradient equals the single-process
+gradient: ``world * (w1 * l1 + w3 * l3) + w2 * l2``.  The smooth term is a per-shard mean whose
+average over equally sized shards already is the global one -- scaling it too would weight it
+world times too heavily (train.py: train_step does exactly this).
 """
 from __future__ import annotations
 

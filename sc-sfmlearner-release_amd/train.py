@@ -135,6 +135,16 @@ def build_datasets(args):
 def main():
     global best_error, n_iter, device
     args = parser.parse_args()
+    if args.with_pretrain:
+        # the reference's default (--with-pretrain 1, train.py:53) downloads ImageNet weights; say so before any
+        # dataset is crawled rather than from inside model construction
+        from models.resnet_encoder import imagenet_weights_path
+        missing = [n for n in sorted({args.resnet_layers, 18}) if imagenet_weights_path(n) is None]
+        if missing:
+            parser.error("--with-pretrain 1 needs ImageNet weights, which cannot be downloaded here: put "
+                         + ", ".join("resnet{}.pth".format(n) for n in missing)
+                         + " (torchvision state dicts) in a directory named by SCSFM_IMAGENET_WEIGHTS, or pass "
+                           "--with-pretrain 0 (optionally with --pretrained-disp / --pretrained-pose)")
     rank, local_rank, world = hip_dist.init_process_group_from_env()
     is_main = rank == 0
     if torch.cuda.is_available():
@@ -189,9 +199,8 @@ def main():
 
     if world > 1:
         # gradients: one bucketed all-reduce per step over RCCL / xGMI, overlapped with backward
-        ddp = torch.nn.parallel.DistributedDataParallel
-        disp_net = ddp(disp_net, device_ids=[local_rank], bucket_cap_mb=64, gradient_as_bucket_view=True)
-        pose_net = ddp(pose_net, device_ids=[local_rank], bucket_cap_mb=64, gradient_as_bucket_view=True)
+        freeze_unused_scale_heads(disp_net, args.num_scales)
+        disp_net, pose_net = wrap_ddp(disp_net, local_rank), wrap_ddp(pose_net, local_rank)
         if args.exact_mask_normalisation:
             hip_dist.enable_exact_normalisation()
     args.world = world
@@ -250,27 +259,64 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def freeze_unused_scale_heads(disp_net, num_scales):
+    """In train mode DispResNet returns four scales (DispResNet.py:118-119) but the loss reads only the first
+    ``--num-scales`` of them (loss_functions.py:55; every reference script passes 1), so the output convolutions
+    of the other scales never receive a gradient.  Single-process that is harmless (Adam skips parameters
+    whose .grad is None); DistributedDataParallel, however, waits for every trainable parameter and raises at the
+    second iteration.  Marking those heads as not trainable changes nothing numerically -- they stay in the
+    state dict at their initial values exactly as in the reference -- and keeps DDP's bucket bookkeeping static."""
+    net = disp_net.module if hasattr(disp_net, "module") else disp_net
+    dec = net.decoder
+    for scale, idx in dec._head.items():
+        if scale >= num_scales:
+            for p in dec.decoder[idx].parameters():
+                p.requires_grad_(False)
+
+
+def wrap_ddp(net, local_rank=None):
+    """One process per GPU: bucketed all-reduce of the gradients (RCCL over xGMI; gloo on CPU), overlapped with
+    backward.  ``broadcast_buffers=False``: each net runs several forwards per step before the one backward
+    (3x DispResNet, 4x PoseResNet at sequence length 3, train.py:426-444) and DDP's default re-broadcast of the
+    BatchNorm running statistics at the start of every forward rewrites, in place, buffers the earlier forwards
+    saved for their backward.  BatchNorm statistics are per replica, as under the reference's nn.DataParallel
+    (train.py:168-169); rank 0's are what is checkpointed."""
+    ddp = torch.nn.parallel.DistributedDataParallel
+    ids = [local_rank] if (local_rank is not None and next(net.parameters()).is_cuda) else None
+    return ddp(net, device_ids=ids, bucket_cap_mb=64, gradient_as_bucket_view=True, broadcast_buffers=False)
+
+
 def train_step(args, disp_net, pose_net, optimizer, tgt_img, ref_imgs, intrinsics):
-    """One optimisation step on device tensors (train.py:258-282).  Returns the four losses (tensors)."""
+    """One optimisation step on device tensors (train.py:258-282).  Returns the four losses (tensors).
+
+    Exact mask normalisation at world > 1: every rank holds the GLOBAL photo / geometry losses (with gradients
+    w.r.t. its own shard) and DDP averages gradients, so those two terms enter the differentiated sum multiplied
+    by the world size; the smooth term is a per-shard mean whose average over ranks already is the global one.
+    The returned ``loss`` is the unscaled w1*l1 + w2*l2 + w3*l3."""
     w1, w2, w3 = args.photo_loss_weight, args.smooth_loss_weight, args.geometry_consistency_weight
+    scale = getattr(args, 'world', 1) if getattr(args, 'exact_mask_normalisation', False) else 1
     tgt_depth, ref_depths = compute_depth(disp_net, tgt_img, ref_imgs)
     poses, poses_inv = compute_pose_with_inv(pose_net, tgt_img, ref_imgs)
     if getattr(args, 'single_loss_node', 1) and compute_total_loss is not None:
         # the three lines of the reference below as one autograd node (same values and gradients, fewer launches)
-        loss, loss_1, loss_2, loss_3 = compute_total_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, poses,
-                                                          poses_inv, args.num_scales, args.with_ssim, args.with_mask,
-                                                          args.with_auto_mask, args.padding_mode, w1, w2, w3)
+        objective, loss_1, loss_2, loss_3 = compute_total_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, poses,
+                                                               poses_inv, args.num_scales, args.with_ssim, args.with_mask,
+                                                               args.with_auto_mask, args.padding_mode, w1 * scale, w2,
+                                                               w3 * scale)
     else:  # train.py:259-268 verbatim
         loss_1, loss_3 = compute_photo_and_geometry_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, poses,
                                                          poses_inv, args.num_scales, args.with_ssim, args.with_mask,
                                                          args.with_auto_mask, args.padding_mode)
         loss_2 = compute_smooth_loss(tgt_depth, tgt_img, ref_depths, ref_imgs)
-        loss = w1 * loss_1 + w2 * loss_2 + w3 * loss_3
+        objective = (w1 * scale) * loss_1 + w2 * loss_2 + (w3 * scale) * loss_3
     optimizer.zero_grad(set_to_none=True)
-    # exact mode: every rank holds the GLOBAL loss and DDP averages gradients -> scale by the world size
-    scale = getattr(args, 'world', 1) if getattr(args, 'exact_mask_normalisation', False) else 1
-    (loss * scale if scale != 1 else loss).backward()
+    objective.backward()
     optimizer.step()
+    if scale == 1:
+        loss = objective
+    else:
+        with torch.no_grad():
+            loss = w1 * loss_1.detach() + w2 * loss_2.detach() + w3 * loss_3.detach()
     return loss, loss_1, loss_2, loss_3
 
 

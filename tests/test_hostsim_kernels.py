@@ -311,6 +311,31 @@ def test_speculative_forward_fp64(lib, hint, upstream):
         assert _rel(g_p[i], z(pp[i])) < 1e-10 and _rel(g_pi[i], z(pi[i])) < 1e-10
 
 
+def test_repeated_backward_after_a_failed_speculation(lib):
+    """retain_graph-style use of one workspace: a backward whose upstream gradients do not stand in the hinted
+    ratio (device-side fallback: the speculative planes are overwritten with final values), then one whose
+    gradients do.  The second must not rescale the first one's planes."""
+    d = synth.make_batch(4, 72, 100, n_ref=1, seed=31, depth="smooth")  # enough pixels to open both gates
+    c = lambda x: x.double().contiguous()
+    ti, K = c(d["tgt_img"]), c(d["intrinsics"])
+    ris = [c(r) for r in d["ref_imgs"]]
+    tds, rds = [c(d["tgt_depth"][0])], [[c(r[0])] for r in d["ref_depths"]]
+    ps, pis = [c(p) for p in d["poses"]], [c(p) for p in d["poses_inv"]]
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    _, geom, _, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=(1.0, 0.5))
+    assert float(geom) > 0  # the geometry gate is open: the upstream ratio matters
+    t = lambda v: torch.tensor([v], dtype=torch.float64)
+    for up in ((1.0, 0.0), (1.0, 0.5), (0.3, 0.9), (2.0, 1.0)):
+        td, rd = [leaf(x) for x in tds], [[leaf(x) for x in r] for r in rds]
+        pp, pi = [leaf(p) for p in ps], [leaf(p) for p in pis]
+        po, go = O.photo_and_geometry_loss(ti, ris, K, td, rd, pp, pi, 1, 1, 1, 1, "zeros")
+        (up[0] * po + up[1] * go).backward()
+        g_td, g_rd, g_p, g_pi = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, t(up[0]), t(up[1]))
+        assert _rel(g_td[0], td[0].grad) < 1e-10, up
+        assert _rel(g_rd[0][0], rd[0][0].grad) < 1e-10, up
+        assert _rel(g_p[0], pp[0].grad) < 1e-10 and _rel(g_pi[0], pi[0].grad) < 1e-10, up
+
+
 @pytest.mark.parametrize("hint", [(1.0, 0.5), None])
 def test_more_pair_directions_than_one_launch_holds(lib, hint):
     """3 refs x 2 scales x 2 directions = 12 pair-directions > kMaxPairs (8): the library splits them
