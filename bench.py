@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
-"""Benchmark of the SC-SfMLearner warp + loss hot path on MI355X.
+"""Benchmark of SC-SfMLearner training on MI355X: BASELINE.json's metric, "train images/sec (+ warp-loss ms/step)
+KITTI 256x832 RN18".
 
     python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one synthetic batch, exactly as train.py:262-268,280-281
-drives it: compute_photo_and_geometry_loss (2 refs x 2 directions) + compute_smooth_loss (3 frames),
-the weighted sum (1 / 0.1 / 0.5) and its backward down to the depth maps and poses.  Workload =
-BASELINE.json configs[1]: KITTI 256x832, batch 12 per GPU, sequence length 3, SSIM + mask + auto-mask,
-zeros padding, 1 scale; inputs are resident in HBM before the timed region.  Data-parallel runs
-shard by batch (weak scaling, 12 samples per GPU) with no collective on the loss path.
+One timed "step" = one whole training step exactly as train.py:249-286 runs it (this repo's train.train_step):
+3 DispResNet18 + 4 PoseResNet18 forwards (PyTorch-ROCm / MIOpen, fp32), the HIP warp + loss hot path
+(compute_photo_and_geometry_loss over 2 refs x 2 directions + compute_smooth_loss over 3 frames + the weighted
+sum 1 / 0.1 / 0.5), backward through both, Adam.  Workload = BASELINE.json configs[1]: KITTI 256x832, batch 12
+per GPU, sequence length 3, SSIM + mask + auto-mask, zeros padding, 1 scale; synthetic batch resident in HBM,
+random-init nets.  N > 1: one process per GPU, DistributedDataParallel (bucketed RCCL all-reduce of 26.8 M fp32
+gradients per step), weak scaling (12 samples per GPU), no collective on the loss path.
+`value` = global_batch * K / max-over-ranks elapsed time of the K timed steps.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (pair_fwd_spec_kernel: the speculative forward = warp + losses + both
-                  backward passes of all pair-directions in one launch): algorithmic bytes per launch (SURVEY 8d:
-                  48 B/pixel per pair-direction forward + backward x B*H*W x pair-directions) / its
-                  average launch duration measured here with HIP events on the launching stream, against
-                  the 8 TB/s HBM3E peak
-  cpu_baseline -- the CPU oracle (restatement of the reference's loss path on the same ATen CPU ops)
-                  timed on this host's cores on a bounded sample (cfg0: batch 4), rank 0, N=1 only
+The hot path alone (the part this repo implements as hand-written HIP kernels; 0.5 % of the training step) is
+measured beside it over --loss-steps steps on depth maps / poses resident in HBM: `warp_loss_ms_per_step`,
+`hot_path_images_per_sec`, and
+  roofline     -- the dominant kernel (pair_fwd_spec_kernel: warp + losses + both backward passes of all
+                  pair-directions in one launch): algorithmic bytes per launch (48 B/pixel per
+                  pair-direction forward + backward x B*H*W x pair-directions) / its average launch duration
+                  measured here with HIP events on the launching stream, against the 8 TB/s HBM3E peak
+  cpu_baseline -- the reference's CPU loss path (the unmodified reference when /root/reference is mounted -- never
+                  on the GPU box -- else the oracle, its restatement on the same ATen CPU ops) forward + backward on
+                  this host's cores, bounded sample, rank 0, N=1 only
 """
 import argparse
 import json
@@ -37,6 +42,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy rate
 W_PHOTO, W_SMOOTH, W_GEOM = 1.0, 0.1, 0.5  # train.py:45-47 defaults used by scripts/train_resnet18_depth_256.sh
+DOMINANT_KERNEL = "pair_fwd_spec_kernel<float,true,7u>"
 
 
 def log(*a):
@@ -148,10 +154,11 @@ def time_kernels(x, flags, iters, n_ref):
     return {k: _event_time(fn, iters) for k, fn in calls.items()}
 
 
-def e2e_train(args, device, world, local_rank, barrier):
-    """Whole training step of BASELINE.json's metric (train.py:249-286): 3 DispResNet18 + 4 PoseResNet18
+def e2e_train(args, device, world, dev_index, barrier):
+    """K timed whole training steps of BASELINE.json's metric (train.py:249-286): 3 DispResNet + 4 PoseResNet18
     forwards (PyTorch-ROCm / MIOpen), the HIP loss path, backward, Adam; data parallel with
-    DistributedDataParallel over RCCL when world > 1.  Synthetic batch resident in HBM, random-init nets."""
+    DistributedDataParallel (train.wrap_ddp) when world > 1.  Synthetic batch resident in HBM, random-init nets.
+    W untimed warm-up steps, then exactly K steps between barrier + synchronize, max over ranks."""
     import argparse as _ap
 
     import models
@@ -160,106 +167,127 @@ def e2e_train(args, device, world, local_rank, barrier):
     targs = _ap.Namespace(photo_loss_weight=W_PHOTO, smooth_loss_weight=W_SMOOTH, geometry_consistency_weight=W_GEOM,
                           num_scales=1, with_ssim=1, with_mask=1, with_auto_mask=1, padding_mode="zeros", world=world,
                           exact_mask_normalisation=False)
-    disp_net = models.DispResNet(18, False).to(device).train()
+    disp_net = models.DispResNet(args.resnet_layers, False).to(device).train()
     pose_net = models.PoseResNet(18, False).to(device).train()
+    n_grad = 0
     if world > 1:
-        ddp = torch.nn.parallel.DistributedDataParallel
-        disp_net = ddp(disp_net, device_ids=[local_rank], bucket_cap_mb=64, gradient_as_bucket_view=True)
-        pose_net = ddp(pose_net, device_ids=[local_rank], bucket_cap_mb=64, gradient_as_bucket_view=True)
+        T.freeze_unused_scale_heads(disp_net, targs.num_scales)
+        disp_net, pose_net = T.wrap_ddp(disp_net, dev_index), T.wrap_ddp(pose_net, dev_index)
     params = [{"params": [p for p in disp_net.parameters() if p.requires_grad]},
               {"params": [p for p in pose_net.parameters() if p.requires_grad]}]
+    n_grad = sum(p.numel() for g in params for p in g["params"])
     opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999))
-    g = torch.Generator().manual_seed(1234 + local_rank)
+    g = torch.Generator().manual_seed(1234 + int(os.environ.get("RANK", 0)))
     mk = lambda: ((torch.rand(args.batch, 3, args.height, args.width, generator=g) - 0.45) / 0.225).to(device)
     tgt, refs = mk(), [mk() for _ in range(args.n_ref)]
     from scsfm_hip import synth
-    K = synth.intrinsics(__import__("numpy").random.default_rng(local_rank), args.batch, args.height, args.width,
-                         args.dataset).to(device)
-    for _ in range(args.e2e_warmup):
+    K = synth.intrinsics(__import__("numpy").random.default_rng(int(os.environ.get("RANK", 0))), args.batch, args.height,
+                         args.width, args.dataset).to(device)
+    for _ in range(args.warmup):
         T.train_step(targs, disp_net, pose_net, opt, tgt, refs, K)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.e2e_steps):
+    for _ in range(args.steps):
         loss = T.train_step(targs, disp_net, pose_net, opt, tgt, refs, K)[0]
     barrier()
     dt = time.perf_counter() - t0
+    ranks = 1
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    return {"train_images_per_sec": round(world * args.batch * args.e2e_steps / dt, 2),
-            "ms_per_step": round(dt / args.e2e_steps * 1e3, 3), "steps": args.e2e_steps, "warmup": args.e2e_warmup,
-            "model": "DispResNet18 + PoseResNet18, random init, fp32", "global_batch": world * args.batch,
-            "parallelism": f"ddp{world} (RCCL all-reduce of 26.8 M fp32 gradients per step)" if world > 1 else "1 GPU",
-            "final_loss": float(loss.detach())}
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one)  # every rank contributed: the number of ranks the collective actually spanned
+        ranks = int(one.item())
+    final = float(loss.detach())
+    if not (final == final and abs(final) < 1e6):
+        raise RuntimeError(f"training diverged in the bench: loss {final}")
+    del disp_net, pose_net, opt
+    return {"elapsed_s": dt, "ranks": ranks, "final_loss": final, "trainable_parameters": n_grad,
+            "model": f"DispResNet{args.resnet_layers} + PoseResNet18, random init, fp32 (MIOpen convolutions)"}
 
 
-def cpu_baseline(args, flags, budget_s):
-    """The oracle (ATen-CPU restatement of the reference loss path) forward + backward on host
-    cores, bounded to ~budget_s seconds; same generator, cfg0 batch size."""
-    from oracle import scsfm_oracle as O
-    from scsfm_hip import synth
-    B = min(4, args.batch)
-    d = synth.make_batch(B, args.height, args.width, n_ref=args.n_ref, seed=0, depth=args.depth,
-                         image="smooth" if args.depth == "smooth" else "iid", dataset=args.dataset)
-    # intra-op threads: the cores this process may use, capped -- the ATen CPU ops of this path stop
-    # scaling (and, oversubscribed, collapse) long before a 256-core host is filled
+def cpu_baseline(args, budget_s):
+    """The reference's CPU loss path forward + backward on host cores (oracle/cpu_baseline.py in a subprocess):
+    the unmodified reference when its tree is mounted (build container), else the oracle in impl='aten' mode (the
+    same ATen CPU ops; the only possibility on the GPU box).  Variants per SURVEY 8d: all usable cores and one
+    thread, the reference's batch (4) and the GPU config's batch, anomaly mode off and -- once -- on
+    (train.py:67).  `value` is the best images/s at the GPU config's batch, anomaly off."""
+    import subprocess
+    ref_dir = "/root/reference"
+    kind = "reference" if os.path.exists(os.path.join(ref_dir, "loss_functions.py")) else "port"
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    # intra-op threads: the cores this process may use, capped -- the ATen CPU ops of this path stop scaling (and,
+    # oversubscribed, collapse: 129 s/step at 256 threads) long before a 256-core host is filled
     cores = max(1, min(avail, args.cpu_threads))
-    torch.set_num_threads(cores)
+    b_ref, b_gpu = min(4, args.batch), args.batch
+    variants = [(cores, b_gpu, 0), (cores, b_ref, 0), (1, b_ref, 0), (cores, b_ref, 1)]
+    variants = list(dict.fromkeys(variants))
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--impl", "reference" if kind == "reference" else "oracle",
+           "--variants", ",".join(f"{t}:{b}:{a}" for t, b, a in variants), "--seconds", str(budget_s),
+           "--height", str(args.height), "--width", str(args.width), "--n-ref", str(args.n_ref), "--depth", args.depth,
+           "--dataset", args.dataset]
+    env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH",)}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""  # host cores only
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=env, timeout=max(120.0, 20 * budget_s))
+    if out.returncode != 0:
+        raise RuntimeError("cpu baseline failed: " + out.stderr[-2000:])
+    rows = json.loads(out.stdout.strip().split("\n")[-1])
+    head = max((r for r in rows if r["batch"] == b_gpu and not r["anomaly_mode"]), key=lambda r: r["images_per_sec"])
+    n_px = head["batch"] * args.height * args.width
+    return {"value": head["images_per_sec"], "unit": "images/s (loss path only, fwd+bwd)", "cores": head["threads"], "kind": kind,
+            "sample": f"{'unmodified reference loss_functions.py' if kind == 'reference' else 'oracle (ATen CPU ops of the reference path)'} "
+                      f"fwd+bwd, batch {head['batch']} x {args.height}x{args.width}, {args.n_ref} refs, median of "
+                      f"{head['timed_steps']} steps ({head['ms_per_step']} ms/step); other thread counts / batch / "
+                      f"anomaly mode under `variants`",
+            "ms_per_step": head["ms_per_step"],
+            "algorithmic_GBs": round(step_bytes(n_px, args.n_ref) / (head["ms_per_step"] * 1e-3) / 1e9, 3),
+            "host_cores_available": avail, "variants": rows}
 
-    def one():
-        lf = lambda t: t.clone().requires_grad_(True)
-        td = [lf(t) for t in d["tgt_depth"]]
-        rd = [[lf(t) for t in r] for r in d["ref_depths"]]
-        ps, pi = [lf(p) for p in d["poses"]], [lf(p) for p in d["poses_inv"]]
-        photo, geom = O.photo_and_geometry_loss(d["tgt_img"], d["ref_imgs"], d["intrinsics"], td, rd, ps, pi, 1,
-                                                *flags, impl="aten")
-        smooth = O.smooth_loss(td, d["tgt_img"], rd, d["ref_imgs"])
-        (W_PHOTO * photo + W_SMOOTH * smooth + W_GEOM * geom).backward()
 
-    t0 = time.perf_counter()
-    one()  # warm-up
-    warm = time.perf_counter() - t0
-    times = []
-    t_end = time.perf_counter() + max(0.0, budget_s - warm)
-    while time.perf_counter() < t_end or len(times) < 1:
-        t0 = time.perf_counter()
-        one()
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(B / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (ATen CPU ops of the reference path) fwd+bwd, batch {B} x {args.height}x{args.width}, "
-                      f"{args.n_ref} refs, median of {len(times)} steps ({med * 1e3:.1f} ms/step)",
-            "ms_per_step": round(med * 1e3, 2),
-            "algorithmic_GBs": round(step_bytes(B * args.height * args.width, args.n_ref) / med / 1e9, 3)}
+def library_identity(lib):
+    """Which binary served the run: resolved path, ABI version, size + sha256 of the .so and of the sources it was
+    built from (csrc/*, include/scsfm_hip.h)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(PKG, "csrc", "*"))) + [os.path.join(ROOT, "include", "scsfm_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    blob = open(lib.path, "rb").read()
+    return {"path": os.path.realpath(lib.path), "abi_version": int(lib._dll.scsfm_abi_version()), "bytes": len(blob),
+            "so_sha256_16": hashlib.sha256(blob).hexdigest()[:16], "source_sha256_16": h.hexdigest()[:16],
+            "env_override": bool(os.environ.get("SCSFM_HIP_LIB"))}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=50, help="timed whole-training steps (K)")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed training steps before them (W)")
     ap.add_argument("--batch", type=int, default=12, help="samples per GPU (configs[1]: 12)")
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=832)
     ap.add_argument("--n-ref", type=int, default=2, help="sequence length - 1")
     ap.add_argument("--dataset", default="kitti", choices=["kitti", "nyu"])
+    ap.add_argument("--resnet-layers", type=int, default=18, choices=[18, 50], help="DispResNet encoder (configs[3]: 50)")
     ap.add_argument("--depth", default="smooth", choices=["smooth", "iid"],
-                    help="synthetic depth law: smooth = realistic locality (headline), iid = incoherent gathers")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline (0 = skip)")
+                    help="synthetic depth law of the hot-path legs: smooth = realistic locality (headline), iid = "
+                         "incoherent gathers")
+    ap.add_argument("--loss-steps", type=int, default=50, help="timed steps of the hot-path (loss only) legs")
+    ap.add_argument("--loss-warmup", type=int, default=10)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on the CPU baseline's intra-op threads")
     ap.add_argument("--kernel-iters", type=int, default=30)
-    ap.add_argument("--e2e-steps", type=int, default=20, help="timed whole-training steps with the nets (0 = skip)")
-    ap.add_argument("--e2e-warmup", type=int, default=5)
+    ap.add_argument("--e2e", type=int, default=1, help="0: skip the training steps and report the hot path alone "
+                                                      "(profiling runs); `value` is then the hot-path rate and says so")
     ap.add_argument("--graph", type=int, default=1,
-                    help="1: time the step as a HIP-graph replay (scsfm_hip.graphs.GraphedStep; the eager figure is "
-                         "reported beside it) when running on one GPU, 2: also under torchrun, 0: eager launches only")
+                    help="1: also time the hot-path step as a HIP-graph replay (scsfm_hip.graphs.GraphedStep) when "
+                         "running on one GPU, 2: also under torchrun, 0: eager launches only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -277,9 +305,11 @@ def main():
     dev_index = 0 if shared_gpu else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if shared_gpu else "nccl"
         if shared_gpu:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
@@ -289,9 +319,10 @@ def main():
     from scsfm_hip import _lib
     lib = _lib.get()
     assert lib.path.endswith(".so") and os.path.exists(lib.path)  # the HIP library, never a fallback
+    ident = library_identity(lib)
+    assert ident["abi_version"] == 3, ident
 
     flags = (1, 1, 1, "zeros")  # with_ssim, with_mask, with_auto_mask, padding_mode (scripts/train_resnet18_depth_256.sh)
-    x, _ = make_inputs(args, seed=rank, device=device)
 
     def barrier():
         torch.cuda.synchronize()
@@ -299,15 +330,39 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # ---------------------------------------------------------------------------------------------------
+    # 1. BASELINE.json's metric: whole training steps (nets + HIP loss path + backward + Adam), W warm-up + K timed
+    # ---------------------------------------------------------------------------------------------------
+    e2e = None
+    if args.e2e:
+        try:
+            e2e = e2e_train(args, device, world, dev_index, barrier)
+        except Exception as exc:
+            import traceback
+            traceback.print_exc()
+            log(f"bench.py: the training step failed: {type(exc).__name__}: {exc}")
+            if world > 1:
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+            sys.exit(3)  # a broken training step is a broken bench: no JSON line, non-zero status
+        torch.cuda.empty_cache()
+
+    # ---------------------------------------------------------------------------------------------------
+    # 2. the hot path alone (loss forward + backward on resident depth maps / poses)
+    # ---------------------------------------------------------------------------------------------------
+    x, _ = make_inputs(args, seed=rank, device=device)
+
     def timed(step_fn, before_timed=None):
-        """W untimed + exactly K timed steps between barrier + synchronize; max over ranks."""
-        for _ in range(args.warmup):
+        """loss-warmup untimed + exactly loss-steps timed steps between barrier + synchronize; max over ranks."""
+        for _ in range(args.loss_warmup):
             o = step_fn()
         barrier()
         if before_timed is not None:
             before_timed()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.loss_steps):
             o = step_fn()
         barrier()
         dt = time.perf_counter() - t0
@@ -318,9 +373,9 @@ def main():
         return dt, o
 
     # eager: every kernel launched from Python each step (the way train.py calls the loss functions)
-    # ... with the library's measurement hook on: every launch of the dominant kernel inside the K timed steps is
+    # ... with the library's measurement hook on: every launch of the dominant kernel inside the timed steps is
     # bracketed by HIP events on the stream it is launched on (scsfm_profile_begin / _end)
-    eager_elapsed, out = timed(lambda: hot_path_step(LF, x, flags), lambda: lib.call("scsfm_profile_begin", args.steps))
+    eager_elapsed, out = timed(lambda: hot_path_step(LF, x, flags), lambda: lib.call("scsfm_profile_begin", args.loss_steps))
     import ctypes
     prof_mean, prof_min, prof_n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
     lib.call("scsfm_profile_end", ctypes.addressof(prof_mean), ctypes.addressof(prof_min), ctypes.addressof(prof_n))
@@ -329,16 +384,17 @@ def main():
     del out  # nothing may keep the eager step's autograd graph (and its stream-bound AccumulateGrad nodes) alive
     import gc
     gc.collect()
-    elapsed, launch = eager_elapsed, "eager launches from Python"
-    # extension leg, eager: the step behind ONE autograd node (compute_total_loss).  Measured before any graph is
-    # captured: a live capture keeps stream-bound autograd nodes alive and slows later eager steps down.
+    loss_elapsed, launch = eager_elapsed, "eager launches from Python"
+    # extension leg, eager: the step behind ONE autograd node (compute_total_loss; what this repo's train.py uses).
+    # Measured before any graph is captured: a live capture keeps stream-bound autograd nodes alive and slows later
+    # eager steps down.
     single = None
     try:
         se, so = timed(lambda: hot_path_step_single_node(LF, x, flags))
         svals = [float(v.detach()) for v in so]
         del so
         gc.collect()
-        single = {"eager_ms_per_step": round(se / args.steps * 1e3, 4),
+        single = {"eager_ms_per_step": round(se / args.loss_steps * 1e3, 4),
                   "losses_match": all(abs(a - b) <= 1e-6 * max(1.0, abs(b)) for a, b in zip(svals, eager_vals))}
     except Exception as exc:
         single = {"error": f"{type(exc).__name__}: {exc}"}
@@ -350,13 +406,13 @@ def main():
         try:
             from scsfm_hip.graphs import GraphedStep
             gs = GraphedStep(lambda: hot_path_step(LF, x, flags))
-            elapsed, out = timed(gs.replay)
+            loss_elapsed, out = timed(gs.replay)
             launch = "HIP graph replay of the captured step (torch.cuda.CUDAGraph)"
             gvals = [float(v.detach()) for v in out]
             assert all(abs(a - b) <= 1e-6 * max(1.0, abs(b)) for a, b in zip(gvals, eager_vals)), (gvals, eager_vals)
         except Exception as exc:  # keep the eager measurement, say why the graph leg is missing
             graph_err = f"{type(exc).__name__}: {exc}"
-            elapsed, gvals = eager_elapsed, eager_vals
+            loss_elapsed, gvals = eager_elapsed, eager_vals
     else:
         gvals = eager_vals
     loss, photo, smooth, geom = gvals
@@ -367,15 +423,15 @@ def main():
             from scsfm_hip.graphs import GraphedStep
             gs1 = GraphedStep(lambda: hot_path_step_single_node(LF, x, flags))
             sg, _ = timed(gs1.replay)
-            single["ms_per_step"] = round(sg / args.steps * 1e3, 4)
+            single["ms_per_step"] = round(sg / args.loss_steps * 1e3, 4)
         except Exception as exc:
             single["graph_error"] = f"{type(exc).__name__}: {exc}"
     gs = gs1 = None  # drop the captures (and the autograd graphs their outputs hold) before the remaining legs
     gc.collect()
 
     n_px = args.batch * args.height * args.width
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * args.batch * args.steps / elapsed
+    loss_ms = loss_elapsed / args.loss_steps * 1e3
+    hot_rate = world * args.batch * args.loss_steps / loss_elapsed
 
     kt = time_kernels(x, flags, args.kernel_iters, args.n_ref)
     n_pairs = 2 * args.n_ref
@@ -385,11 +441,11 @@ def main():
     # launch: per pair-direction both images and both depth maps are read once (32 B/px) and the
     # two depth gradients are written once and read-modify-written once (16 B/px).
     spec_bytes = n_pairs * 48 * n_px
-    # its average duration over the launches inside the K timed (eager) steps; the back-to-back figure of
+    # its average duration over the launches inside the timed (eager) steps; the back-to-back figure of
     # time_kernels (inputs still in the Infinity Cache from the previous launch) is reported beside it
     launch_s = in_step_us[0] * 1e-6 if in_step_us[2] > 0 else kt["spec_kernel_only"]
     achieved = spec_bytes / launch_s / 1e9
-    roofline = {"bound": "hbm", "kernel": f"pair_fwd_spec_kernel<float,true,7u> ({n_pairs} pair-directions per launch)",
+    roofline = {"bound": "hbm", "kernel": f"{DOMINANT_KERNEL} ({n_pairs} pair-directions per launch)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, n_pairs),
                 "algorithmic_bytes_per_launch": spec_bytes, "avg_launch_us": round(launch_s * 1e6, 2),
@@ -402,40 +458,50 @@ def main():
                      "frac": round(48 * n_px / pair_t / 1e9 / HBM_PEAK_GBS, 4)}
     kernel_sum = kt["pairs_fwd_spec"] + kt["pairs_bwd_after_spec"] + kt["smooth_fwd"] + kt["smooth_bwd"]
 
-    e2e = None
-    if args.e2e_steps > 0:
-        try:
-            e2e = e2e_train(args, device, world, dev_index, barrier)
-        except Exception as exc:  # the hot-path figures above stay valid; say what happened
-            e2e = {"error": f"{type(exc).__name__}: {exc}"}
-
     if rank == 0:
+        workload = (f"configs[1]: {args.dataset} {args.height}x{args.width}, batch {args.batch}/GPU, {args.n_ref} refs "
+                    f"(seq {args.n_ref + 1}), ResNet{args.resnet_layers} DispNet + ResNet18 PoseNet, ssim+mask+auto-mask, "
+                    f"zeros padding, 1 scale")
+        if e2e is not None:
+            value = world * args.batch * args.steps / e2e["elapsed_s"]
+            ms_per_step = e2e["elapsed_s"] / args.steps * 1e3
+            metric = "train images/sec (+ warp-loss ms/step) KITTI 256x832 RN18"
+            parallelism = (f"ddp{world}: one process per GPU, DistributedDataParallel, bucketed {backend} all-reduce of "
+                           f"{e2e['trainable_parameters'] * 4 / 1e6:.1f} MB of fp32 gradients per step; loss path sharded "
+                           f"by batch, no loss-path collective") if world > 1 else "1 GPU"
+        else:  # --e2e 0 (profiling): say plainly that this is NOT the training rate
+            value, ms_per_step = hot_rate, loss_ms
+            metric = "images/sec through the warp+loss hot path ONLY (--e2e 0: nets and optimizer not run)"
+            parallelism = f"dp{world} (batch shards, no loss-path collective)"
         res = {
-            "metric": "train images/sec through the warp+loss hot path (photo+geometry+smooth, fwd+bwd), "
-                      "KITTI 256x832 seq3",
+            "metric": metric,
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {args.dataset} {args.height}x{args.width}, batch {args.batch}/GPU, "
-                                   f"{args.n_ref} refs (seq {args.n_ref + 1}), ssim+mask+auto-mask, zeros padding, "
-                                   f"1 scale, {args.depth} synthetic depth",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world} (batch shards, no loss-path collective)",
-                       "launch": launch},
-            "warp_loss_ms_per_step": round(ms_per_step, 4),
-            "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
-            "graph_error": graph_err,
-            "single_autograd_node": single,
-            "step_algorithmic_GBs": round(step_bytes(n_px, args.n_ref) / (elapsed / args.steps) / 1e9, 1),
-            "step_frac_of_hbm_peak": round(step_bytes(n_px, args.n_ref) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-            "kernel_us": {k: round(v * 1e6, 2) for k, v in kt.items()},
-            "kernel_sum_ms_per_step": round(kernel_sum * 1e3, 4),
-            "losses": {"total": loss, "photo": photo, "smooth": smooth, "geometry": geom},
+            "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": parallelism},
+            "rccl_ranks": e2e["ranks"] if e2e is not None else world,
+            "collective_backend": backend,
+            "train": None if e2e is None else {"train_images_per_sec": round(value, 2), "ms_per_step": round(ms_per_step, 3),
+                                               "final_loss": e2e["final_loss"], "model": e2e["model"],
+                                               "trainable_parameters": e2e["trainable_parameters"]},
+            # ---- the hot path alone ----
+            "warp_loss_ms_per_step": round(loss_ms, 4),
+            "hot_path_images_per_sec": round(hot_rate, 2),
+            "warp_loss_share_of_train_step": None if e2e is None else round(loss_ms / ms_per_step, 5),
+            "warp_loss": {"launch": launch, "steps": args.loss_steps, "warmup": args.loss_warmup,
+                          "depth_law": args.depth, "eager_ms_per_step": round(eager_elapsed / args.loss_steps * 1e3, 4),
+                          "graph_error": graph_err, "single_autograd_node": single,
+                          "step_algorithmic_GBs": round(step_bytes(n_px, args.n_ref) / (loss_elapsed / args.loss_steps) / 1e9, 1),
+                          "step_frac_of_hbm_peak": round(step_bytes(n_px, args.n_ref) / (loss_elapsed / args.loss_steps) / 1e9 / HBM_PEAK_GBS, 4),
+                          "kernel_us": {k: round(v * 1e6, 2) for k, v in kt.items()},
+                          "kernel_sum_ms_per_step": round(kernel_sum * 1e3, 4),
+                          "losses": {"total": loss, "photo": photo, "smooth": smooth, "geometry": geom},
+                          "pair_direction_roofline": pair_roofline},
             "roofline": roofline,
-            "pair_direction_roofline": pair_roofline,
-            "e2e_train": e2e,
+            "library": ident,
         }
         if world == 1 and args.cpu_seconds > 0:
-            res["cpu_baseline"] = cpu_baseline(args, flags, args.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

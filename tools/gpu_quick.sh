@@ -1,5 +1,5 @@
 set +e
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-python bench.py --steps 50 --warmup 10 --cpu-seconds 0 --e2e-steps 0 2>/dev/null | tee gpurun_out/bench_quick.json | python -c "
+python bench.py --loss-steps 50 --loss-warmup 10 --cpu-seconds 0 --e2e 0 2>/dev/null | tee gpurun_out/bench_quick.json | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['kernel_us'], d['roofline'])"

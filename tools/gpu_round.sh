@@ -11,14 +11,14 @@ mkdir -p $O
 echo "=== smoke"; python __graft_entry__.py --smoke > $O/smoke_$TAG.log 2>&1; echo "smoke rc=$?"; tail -3 $O/smoke_$TAG.log
 echo "=== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu_$TAG.log
 echo "=== bench"; timeout 900 python bench.py --steps 50 --warmup 10 > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc=$?"; cut -c1-2600 $O/bench_$TAG.json; tail -2 $O/bench_$TAG.err
-echo "=== bench iid"; timeout 600 python bench.py --steps 30 --warmup 5 --depth iid --cpu-seconds 0 --e2e-steps 0 > $O/bench_${TAG}_iid.json 2>> $O/bench_$TAG.err; cut -c1-400 $O/bench_${TAG}_iid.json
+echo "=== bench iid"; timeout 600 python bench.py --loss-steps 30 --loss-warmup 5 --depth iid --cpu-seconds 0 --e2e 0 > $O/bench_${TAG}_iid.json 2>> $O/bench_$TAG.err; cut -c1-400 $O/bench_${TAG}_iid.json
 echo "=== bench configs[3] loss path (batch 8) and configs[4] (NYU 256x320, 4 refs, batch 16)"
-timeout 600 python bench.py --steps 30 --warmup 5 --batch 8 --cpu-seconds 0 --e2e-steps 0 > $O/bench_${TAG}_cfg3.json 2>> $O/bench_$TAG.err; cut -c1-330 $O/bench_${TAG}_cfg3.json
-timeout 600 python bench.py --steps 30 --warmup 5 --dataset nyu --height 256 --width 320 --n-ref 4 --batch 16 --cpu-seconds 0 --e2e-steps 0 > $O/bench_${TAG}_cfg4.json 2>> $O/bench_$TAG.err; cut -c1-330 $O/bench_${TAG}_cfg4.json
+timeout 600 python bench.py --loss-steps 30 --loss-warmup 5 --batch 8 --cpu-seconds 0 --e2e 0 > $O/bench_${TAG}_cfg3.json 2>> $O/bench_$TAG.err; cut -c1-330 $O/bench_${TAG}_cfg3.json
+timeout 600 python bench.py --loss-steps 30 --loss-warmup 5 --dataset nyu --height 256 --width 320 --n-ref 4 --batch 16 --cpu-seconds 0 --e2e 0 > $O/bench_${TAG}_cfg4.json 2>> $O/bench_$TAG.err; cut -c1-330 $O/bench_${TAG}_cfg4.json
 cd /tmp
-echo "=== rocprof kernel trace"; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --e2e-steps 0 --graph 0 --kernel-iters 3 > $O/rocprof_$TAG.log 2>&1; echo "rc=$?"
+echo "=== rocprof kernel trace"; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --loss-steps 20 --loss-warmup 5 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 3 > $O/rocprof_$TAG.log 2>&1; echo "rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
-  echo "=== rocprof pmc $C"; timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/prof_$TAG -o pmc_$C -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --e2e-steps 0 --graph 0 --kernel-iters 2 > $O/rocprof_${TAG}_$C.log 2>&1; echo "rc=$?"
+  echo "=== rocprof pmc $C"; timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/prof_$TAG -o pmc_$C -- python $R/bench.py --loss-steps 3 --loss-warmup 1 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 2 > $O/rocprof_${TAG}_$C.log 2>&1; echo "rc=$?"
 done
 cd $R
 python tools/rocprof_summary.py $O/prof_$TAG/trace_results.db | grep -v "at::native\|rocclr" | head -20
