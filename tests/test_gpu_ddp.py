@@ -40,5 +40,5 @@ def test_two_ranks_on_one_gpu_train_step(exact):
         assert p.exitcode == 0
     assert len(results[0]["losses"]) == STEPS
     assert results[0]["losses"][0]["rank"][3] > 0  # geometry gate open
-    worst = S.compare(results, ref_losses, ref_snaps, exact, loss_tol=1e-4, grad_tol=5e-2)
+    worst = S.compare(results, ref_losses, ref_snaps, exact, loss_tol=1e-4, grad_tol=5e-2, later_loss_tol=2e-2)
     print(f"exact={exact}: worst parameter-update mismatch {worst:.2e} of the update")
