@@ -68,9 +68,10 @@ inline PairWs pair_ws_layout(int B, int H, int W) {
   size_t off = (size_t)B * sizeof(BatchConsts<double>);
   l.off_sums = off; off += 16 * sizeof(double);
   // (sized like the partials: the finest tiling that writes them is the fp64 speculative forward's)
-  l.off_gP = off; off += (size_t)B * ceil_div(W, kTileW - 2) * ceil_div(H, 6) * 12 * sizeof(double);
-  // partials: sized for the finest tiling that writes them (62 x 6 outputs per block: the fp64 speculative forward)
-  l.off_partials = off; off += (size_t)ceil_div(W, kTileW - 2) * ceil_div(H, 6) * B * 3 * sizeof(double);
+  l.off_gP = off; off += (size_t)B * ceil_div(W, kTileW - 4) * ceil_div(H, 6) * 12 * sizeof(double);
+  // partials: sized for the finest tiling that writes them (at most 62 x 6 outputs per block of the tiled kernels,
+  // 60-column strips of the speculative forward)
+  l.off_partials = off; off += (size_t)ceil_div(W, kTileW - 4) * ceil_div(H, 6) * B * 3 * sizeof(double);
   l.total = (off + 255) & ~(size_t)255;
   return l;
 }

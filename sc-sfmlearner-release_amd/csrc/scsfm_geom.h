@@ -371,41 +371,56 @@ __device__ __forceinline__ void lds_add(T* p, T v) {
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <typename T, int WW, int WH>
-__device__ __forceinline__ void scatter_taps_window(T (*win)[WW], int wx0, int wy0, T* __restrict__ gplane,
-                                                    const Sample<T>& s, T g) {
+// Cells of the staging windows.  fp32 product path: 32-bit FIXED POINT (2^-20 per unit, range +-2048), because on
+// gfx950 the LDS float atomic is executed lane by lane (ds_add_f32: 1.25 ns per LANE per CU, measured with
+// tools/ubench/rates2.hip) while the integer one is a single pass (ds_add_u32: 2 ns per wave instruction);
+// contributions are rounded to nearest, so a cell's error is at most half a unit per contribution (4.8e-7) whatever
+// the order of the additions -- the window part of the scatter is bit-reproducible.  fp64 (gradient-check builds):
+// plain fp64 cells.
+constexpr float kFixScale = 1048576.0f;
+constexpr float kFixInv = 1.0f / 1048576.0f;
+template <typename T> struct WinCell { typedef int type; };
+template <> struct WinCell<double> { typedef double type; };
+__device__ __forceinline__ void win_add(int* p, float v) { lds_add(p, (int)t_floor(v * kFixScale + 0.5f)); }
+__device__ __forceinline__ void win_add(double* p, double v) { lds_add(p, v); }
+__device__ __forceinline__ void win_add(float* p, float v) { lds_add(p, v); }  // (float cells: see geom_tile)
+__device__ __forceinline__ float win_value(int c) { return float(c) * kFixInv; }
+__device__ __forceinline__ double win_value(double c) { return c; }
+__device__ __forceinline__ float win_value(float c) { return c; }
+
+template <typename T, typename Cell, int WW, int WH>
+__device__ __forceinline__ void scatter_taps_window(Cell (*win)[WW], int wx0, int wy0,
+                                                    T* __restrict__ gplane, const Sample<T>& s, T g) {
   if (g == T(0)) return;
   const int lx = s.x0 - wx0, ly = s.y0 - wy0;
   if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < WH - 1) {
     // unpredicated: an out-of-image tap has weight 0, and adding 0 leaves its cell at the 0 the flush skips
-    // (workgroup scope is what an LDS atomic is; it also keeps the compiler from merging these with the global
-    // atomics of the other branch into flat_atomic instructions on a generic pointer, which it otherwise does)
-    lds_add(&win[ly][lx], g * s.w[0]);
-    lds_add(&win[ly][lx + 1], g * s.w[1]);
-    lds_add(&win[ly + 1][lx], g * s.w[2]);
-    lds_add(&win[ly + 1][lx + 1], g * s.w[3]);
+    win_add(&win[ly][lx], g * s.w[0]);
+    win_add(&win[ly][lx + 1], g * s.w[1]);
+    win_add(&win[ly + 1][lx], g * s.w[2]);
+    win_add(&win[ly + 1][lx + 1], g * s.w[3]);
   } else {
     scatter_taps(gplane, s, g);
   }
 }
 
 // Only cells that received an in-image tap are non-zero, so every flushed cell is a valid pixel.
-template <typename T, int WW, int WH>
-__device__ __forceinline__ void flush_scatter_window(const T (*win)[WW], int wx0, int wy0, T* __restrict__ gplane,
-                                                     int W) {
+template <typename T, typename Cell, int WW, int WH>
+__device__ __forceinline__ void flush_scatter_window(const Cell (*win)[WW], int wx0, int wy0,
+                                                     T* __restrict__ gplane, int W) {
   for (int i = threadIdx.x; i < WW * WH; i += kThreads) {
     const int ly = i / WW, lx = i - ly * WW;
-    const T v = win[ly][lx];
-    if (v != T(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), v);
+    const Cell v = win[ly][lx];
+    if (v != Cell(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), T(win_value(v)));
   }
 }
 
 // The same flush restricted to the cells [cx0, cx1] x [cy0, cy1] of the window (inclusive, window coordinates;
 // clamped into it) that can be non-zero: the bounding box of the block's taps is usually half the window, so
 // half as many atomic instructions are issued, each with (nearly) all of its lanes active.
-template <typename T, int WW, int WH>
-__device__ __forceinline__ void flush_scatter_region(const T (*win)[WW], int wx0, int wy0, int cx0, int cy0, int cx1,
-                                                     int cy1, T* __restrict__ gplane, int W) {
+template <typename T, typename Cell, int WW, int WH>
+__device__ __forceinline__ void flush_scatter_region(const Cell (*win)[WW], int wx0, int wy0, int cx0,
+                                                     int cy0, int cx1, int cy1, T* __restrict__ gplane, int W) {
   cx0 = cx0 < 0 ? 0 : cx0; cy0 = cy0 < 0 ? 0 : cy0;
   cx1 = cx1 > WW - 1 ? WW - 1 : cx1; cy1 = cy1 > WH - 1 ? WH - 1 : cy1;
   const int w = cx1 - cx0 + 1, h = cy1 - cy0 + 1;
@@ -414,8 +429,8 @@ __device__ __forceinline__ void flush_scatter_region(const T (*win)[WW], int wx0
   for (int i = threadIdx.x; i < w * h; i += kThreads) {
     const int ry = int((float(i) + 0.5f) * iw);  // i / w, exact for the few thousand cells of a window
     const int ly = cy0 + ry, lx = cx0 + (i - ry * w);
-    const T v = win[ly][lx];
-    if (v != T(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), v);
+    const Cell v = win[ly][lx];
+    if (v != Cell(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), T(win_value(v)));
   }
 }
 
@@ -438,10 +453,10 @@ __device__ __forceinline__ void window_origin(const BatchConsts<T>& bc, int ax, 
 // returns dL/d tgt_depth(p).  g_dd = dL/d diff_depth(p).
 // (Measured alternatives, both slower: a software pipeline that requests pixel r + 1's taps before pixel r is
 // consumed, and finishing the whole strip's arithmetic before a separate scatter loop over compact records.)
-template <typename T, int WW, int WH>
+template <typename T, typename Cell, int WW, int WH>
 __device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py, T d, const T (&gI)[3], T g_dd,
                                         const T* __restrict__ ref_img, const T* __restrict__ ref_depth,
-                                        unsigned plane, int H, int W, unsigned flags, T (*win)[WW], int wx0, int wy0,
+                                        unsigned plane, int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
                                         T* __restrict__ scatter_plane, T* acc) {
   const Sample<T> s = project_pixel(bc, px, py, d, H, W, flags);
   T gix = T(0), giy = T(0), dx, dy;
@@ -465,7 +480,7 @@ __device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py
   }
   gix += gDp * dDx;
   giy += gDp * dDy;
-  if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp);
+  if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, Cell, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp);
   return pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
 }
 

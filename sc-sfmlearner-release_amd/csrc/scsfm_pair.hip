@@ -23,6 +23,8 @@
 // slide down the strip and every LDS read is a conflict-free row access.  The warped image and
 // the target image of the tile + 1-pixel ring live in LDS; ring positions outside the image hold
 // the reflected pixel (ReflectionPad2d(1)).
+#include <cstdlib>
+
 #include "scsfm_geom.h"
 #include "scsfm_ssim.h"
 
@@ -337,6 +339,10 @@ __device__ __forceinline__ unsigned pairs_to_run(const PairBatch<T>& pb, int npa
 // scheduler sees longer straight-line blocks).
 constexpr unsigned kRuntimeFlags = 0xffffffffu;
 constexpr unsigned kTrainFlags = SCSFM_WITH_SSIM | SCSFM_WITH_MASK | SCSFM_WITH_AUTO_MASK;  // zeros padding
+}  // namespace scsfm
+#include "scsfm_strip.h"  // the speculative forward proper (needs PairArgs / PairBatch / the plane indices above)
+namespace scsfm {
+
 template <typename T, bool kSsim, bool kSpec, unsigned kFlags = kRuntimeFlags>
 __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, const PairBatch<T>& pb, int B, int H,
                                            int W, unsigned flags_arg, const T* __restrict__ g_photo,
@@ -359,9 +365,10 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
   __shared__ double red[kSpec ? (3 + 12) * (kThreads / kWave) : 1];  // the two block sums use disjoint parts
   // kSpec: staging window of the geometry tail's scatter (its height follows the tile's)
   constexpr int WW = kWinW, WH = kWinH * TH / kTileH;
-  __shared__ T win[kSpec ? WH : 1][kSpec ? WW : 1];
+  typedef typename WinCell<T>::type Cell;
+  __shared__ Cell win[kSpec ? WH : 1][kSpec ? WW : 1];
   if constexpr (kSpec) {  // zeroed long before its first use (several barriers lie in between)
-    for (int i = threadIdx.x; i < WW * WH; i += kThreads) (&win[0][0])[i] = T(0);
+    for (int i = threadIdx.x; i < WW * WH; i += kThreads) (&win[0][0])[i] = Cell(0);
   }
 
   // upstream gradient x d(masked mean)/d(sum): zero when the 10000-pixel gate was closed
@@ -576,7 +583,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
       for (int c = 0; c < 3; ++c) {
         if constexpr (kSsim) gI[c] = reinterpret_cast<const T*>(&sXY[c][0][0])[ly * kTileW + col]; else gI[c] = gI_reg[k][c];
       }
-      gd[k] = geom_pixel<T, WW, WH>(bc, px, py, in_d[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
+      gd[k] = geom_pixel<T, Cell, WW, WH>(bc, px, py, in_d[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
                                     wy0, g_scatter, acc);
     }
     // A barrier waits for every outstanding global store / atomic of the wave, so everything that writes to
@@ -595,7 +602,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
         st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gd[k]);
     }
     if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5)))
-      flush_scatter_region<T, WW, WH>(win, wx0, wy0, cx0, cy0, cx1, cy1, g_scatter, W);
+      flush_scatter_region<T, Cell, WW, WH>(win, wx0, wy0, cx0, cy0, cx1, cy1, g_scatter, W);
   }
 }
 
@@ -648,7 +655,10 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
   double* __restrict__ gP = pa.gPp;
   constexpr int ROWS = kGeomRows;  // pixels per thread: a block covers a 64 x (4 ROWS) tile
   __shared__ double red[12 * (kThreads / kWave)];
-  __shared__ T win[kWinH][kWinW];  // staging window of the scatter into dL/d ref_depth
+  // (cells in the working type: this pass runs with the final coefficients, ~1e-5 in magnitude, for which the
+  // fixed-point cells of the speculative forward -- whose values are unscaled -- are too coarse)
+  typedef T Cell;
+  __shared__ Cell win[kWinH][kWinW];  // staging window of the scatter into dL/d ref_depth
   if (T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0)) return;  // as in pass A
   if (spec_valid(sums, g_photo, g_geom)) return;  // the speculative forward already ran this pass in its tail
   const int px = blk.x * kWave + (threadIdx.x & (kWave - 1));
@@ -665,7 +675,7 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
   // a step in one launch: the same depth map is the dense target of one pair and the scatter target of another.
   T* __restrict__ g_dense = pa.gbuf + kPlaneDense * gplane + (size_t)b * plane;
   T* __restrict__ g_scatter = pa.gbuf + kPlaneScatter * gplane + (size_t)b * plane;
-  for (int i = threadIdx.x; i < kWinW * kWinH; i += kThreads) (&win[0][0])[i] = T(0);
+  for (int i = threadIdx.x; i < kWinW * kWinH; i += kThreads) (&win[0][0])[i] = Cell(0);
   __syncthreads();
   int wx0, wy0;
   window_origin<T, kWinW, kWinH>(bc, blk.x * kWave + kWave / 2, blk.y * (kThreads / kWave) * ROWS + 2 * ROWS, tgt_depth,
@@ -690,12 +700,12 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
     const int py = py0 + r;
     if (px >= W || py >= H) continue;
     const T gI[3] = {in_g[r][0], in_g[r][1], in_g[r][2]};
-    const T gd = geom_pixel<T, kWinW, kWinH>(bc, px, py, in_d[r], gI, in_g[r][3], ref_img, ref_depth, plane, H, W, flags,
+    const T gd = geom_pixel<T, Cell, kWinW, kWinH>(bc, px, py, in_d[r], gI, in_g[r][3], ref_img, ref_depth, plane, H, W, flags,
                                              win, wx0, wy0, g_scatter, acc);
     st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), (flags & SCSFM_DEBUG_X2) ? T(0) : gd);
   }
   __syncthreads();
-  if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5))) flush_scatter_window<T, kWinW, kWinH>(win, wx0, wy0, g_scatter, W);
+  if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5))) flush_scatter_window<T, Cell, kWinW, kWinH>(win, wx0, wy0, g_scatter, W);
   if (flags & SCSFM_DEBUG_X3) {  // profiling: keep the partials defined
     if (threadIdx.x == 0)
       for (int i = 0; i < 12; ++i) gP[12 * ((size_t)(b * nby + blk.y) * nbx + blk.x) + i] = 0.0;
@@ -914,6 +924,21 @@ static bool desc_inputs_ok(const scsfm_pair_desc& d) {
   return d.tgt_img && d.ref_img && d.tgt_depth && d.ref_depth && d.pose && d.ws;
 }
 
+// Which kernel serves the speculative forward: the per-wave register pipeline (scsfm_strip.h) or the LDS-tiled
+// kernel (default; SCSFM_SPEC_KERNEL=strip selects the register pipeline for A/B measurements).  Read once per process.
+static bool spec_uses_strips() {
+  static const bool strips = [] {
+    const char* e = getenv("SCSFM_SPEC_KERNEL");
+    return e && e[0] == 's';
+  }();
+  return strips;
+}
+// workgroup-level partial records per image the speculative forward leaves (pose partials, sums)
+template <typename T>
+static int spec_nblk(int H, int W) {
+  return spec_uses_strips() ? strip_nbx(W) * strip_nby(H) : ceil_div(W, kTileW - 2) * ceil_div(H, Tile<T>::kH - 2);
+}
+
 // Forward of up to kMaxPairs pair-directions per launch.  `spec`: every pair has a gbuf and w_photo != 0.
 template <typename T>
 static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags, bool spec,
@@ -926,17 +951,30 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
     const size_t npx = (size_t)B * H * W;
     if (!kernel_only)
       hipLaunchKernelGGL((pairs_zero_prep_kernel<T>), dim3(1024, n), dim3(kThreads), 0, stream, pb, npx, n, B, K);
-    grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
     const T r_hint = T(3.0 * w_geom / w_photo);
     const bool timed = g_profile.used < g_profile.n;
     if (timed) (void)hipEventRecord(g_profile.start[g_profile.used], stream);
-    if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags)
-      hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true, kTrainFlags>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags,
-                         r_hint);
-    else if (flags & SCSFM_WITH_SSIM)
-      hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags, r_hint);
-    else
-      hipLaunchKernelGGL((pair_fwd_spec_kernel<T, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags, r_hint);
+    if (spec_uses_strips()) {
+      // one wave per (pair, batch element, 32-row segment, 60-column strip); kStripWaves of them per workgroup
+      const int nbx = strip_nbx(W), nby = strip_nby(H), nunits = nbx * nby * n * B;
+      grid = dim3(nbx, nby, n * B);  // (what the finalize kernel sizes its reduction by: units per pair = nbx * nby * B)
+      const dim3 launch_grid(ceil_div(nunits, kStripWaves));
+      if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags)
+        hipLaunchKernelGGL((pair_strip_kernel<T, kTrainFlags>), launch_grid, dim3(kThreads), 0, stream, pb, B, H, W, nbx, nby,
+                           nunits, flags, r_hint);
+      else
+        hipLaunchKernelGGL((pair_strip_kernel<T>), launch_grid, dim3(kThreads), 0, stream, pb, B, H, W, nbx, nby, nunits,
+                           flags & ~SCSFM_DEBUG_KERNEL_ONLY, r_hint);
+    } else {
+      grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
+      if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags)
+        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true, kTrainFlags>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags,
+                           r_hint);
+      else if (flags & SCSFM_WITH_SSIM)
+        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags, r_hint);
+      else
+        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags, r_hint);
+    }
     if (timed) (void)hipEventRecord(g_profile.stop[g_profile.used++], stream);
   } else {
     hipLaunchKernelGGL((pairs_prep_kernel<T>), dim3(ceil_div(n * B, 64)), dim3(64), 0, stream, pb, n, B, K);
@@ -1009,8 +1047,8 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
                          g_photo, g_geom);
     }
     if (flags & SCSFM_DEBUG_SKIP_GEOM) {
-      hipLaunchKernelGGL((pairs_pose_reduce_kernel<T>), dim3(m * B), dim3(kWave), 0, stream, pb, B, nax * nay, nbx * nby, K,
-                         g_photo, g_geom);
+      hipLaunchKernelGGL((pairs_pose_reduce_kernel<T>), dim3(m * B), dim3(kWave), 0, stream, pb, B, spec_nblk<T>(H, W),
+                         nbx * nby, K, g_photo, g_geom);
     } else {
       // group the private planes by the caller's destination buffer: a pair's dense plane belongs to its
       // target depth map, its scatter plane to its reference depth map
@@ -1040,7 +1078,7 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
       gx = gx < gpose ? gpose : gx;
       // (+ 1 row of workgroups: dL/dpose)
       hipLaunchKernelGGL((pairs_combine_kernel<T>), dim3(gx, cb.nd + 1), dim3(kThreads), 0, stream, cb, npx, pb, m, B,
-                         nax * nay, nbx * nby, K, g_photo, g_geom);
+                         spec_nblk<T>(H, W), nbx * nby, K, g_photo, g_geom);
     }
   }
   return launch_status();

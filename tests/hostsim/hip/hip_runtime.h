@@ -235,3 +235,24 @@ static inline int __float2int_rd(float x) { return (int)floorf(x); }
 #define __builtin_amdgcn_readfirstlane(x) (x)
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+
+// DPP wave shifts (v_*_dpp wave_shr:1 = 0x138: lane <- lane - 1; wave_shl:1 = 0x130: lane <- lane + 1); lanes without a
+// source keep `old`, or read 0 with bound_ctrl
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool bound_ctrl) {
+  const int lane = hostsim::S().cur % 64;
+  const int from = ctrl == 0x138 ? lane - 1 : (ctrl == 0x130 ? lane + 1 : -1000);
+  if (from == -1000) { fprintf(stderr, "hostsim: unsupported dpp_ctrl %x\n", ctrl); abort(); }
+  const int got = hostsim::shfl(src, from);
+  hostsim::State& s = hostsim::S();
+  const int w = s.cur / 64;
+  int nl = s.nthreads - w * 64; if (nl > 64) nl = 64;
+  if (from < 0 || from >= nl) return bound_ctrl ? 0 : old;
+  return got;
+}
+static inline float __builtin_amdgcn_fmed3f(float x, float a, float b) {
+  // median of three; NaN-safe the way the hardware is (a NaN operand yields the minimum of the others)
+  if (x != x) return a < b ? a : b;
+  const float lo = a < b ? a : b, hi = a < b ? b : a;
+  return x < lo ? lo : (x > hi ? hi : x);
+}
+static inline void __builtin_amdgcn_wave_barrier() { hostsim::wave_barrier(); }
