@@ -78,13 +78,13 @@ template <typename T>
 struct StripRow {
   T x[3], y[3];      // target / warped colours
   T coef, m, l1;     // m (1 - diff_depth) [or m], mask, sum_c clamp(|x_c - y_c|)
-  T dIx[3], dIy[3];  // d warped colour / d (ix, iy)
-  T dDx, dDy;        // d sampled depth / d (ix, iy)
-  T gZc, gDpc;       // d diff_depth / d Z, d diff_depth / d D_p (0 outside the clamp)
+  T dIx[3], dIy[3];  // d warped colour / d (X/Z, Y/Z): the sampler's d / d(ix, iy) times d ix / d (X/Z) = (W/2)(2/(W-1)),
+                     // or 0 where the coordinate was overwritten / clipped
+  T dDx, dDy;        // likewise for the sampled depth
+  T gZc, gDpc;       // d diff_depth / d Z (times the Z >= 1e-3 gate), d diff_depth / d D_p (0 outside the clamp)
   T wxa, wxb, wya, wyb;  // bilinear weights of the tap pair's columns / of the two tap rows
   unsigned tap;      // (row << 16) | column of the first tap (clamped into the image)
-  T X, Y, iz, d;     // A cam + c (first two rows), 1 / Z, target depth
-  T kx, ky, zg;      // d xn-gradient factor: (W/2)(2/(W-1)) or 0 where the coordinate was overwritten / clipped; Z gate
+  T Xz, Yz, iz, d;   // gate * X / Z^2, gate * Y / Z^2 (what d Z' takes from the x / y gradients), 1 / Z, target depth
 };
 
 template <typename T>
@@ -104,8 +104,10 @@ struct StripUnit {
   bool col_in, own_x, border_cols;
   const T* __restrict__ tgt_img; const T* __restrict__ ref_img; const T* __restrict__ tgt_depth; const T* __restrict__ ref_depth;
   T* __restrict__ g_dense; T* __restrict__ g_scatter;
-  BatchConsts<T> bc;
-  T kx0, ky0, kz0, inv_w, inv_h, wl, wr, r_hint;
+  // q = (A K^-1)(u, v, 1) = qc + qv * v: X = q_x d + c_x, ... (the column part qc per lane, the rest wave-uniform)
+  T qcx, qcy, qcz, qvx, qvy, qvz, c0, c1, c2;
+  T Kinv[9];  // only for the unit's epilogue (dL/dA from the sums accumulated against d (u, v, 1))
+  T uf, inv_w, inv_h, wl, wr, r_hint;
   Cell* __restrict__ win;
   int wx0, wy0;
   // ---- pipeline state ----
@@ -135,11 +137,9 @@ struct StripUnit {
 #pragma unroll
     for (int c = 0; c < 3; ++c) { ct[c] = nt[c]; cr[c] = nr[c]; }
     const T vf = T(v);
-    const T rx = kx0 + bc.Kinv[1] * vf, ry = ky0 + bc.Kinv[4] * vf, rz = kz0 + bc.Kinv[7] * vf;
-    const T cx = rx * d, cy = ry * d, cz = rz * d;
-    const T X = bc.A[0] * cx + bc.A[1] * cy + bc.A[2] * cz + bc.c[0];
-    const T Y = bc.A[3] * cx + bc.A[4] * cy + bc.A[5] * cz + bc.c[1];
-    const T Zraw = bc.A[6] * cx + bc.A[7] * cy + bc.A[8] * cz + bc.c[2];
+    const T X = (qcx + qvx * vf) * d + c0;         // A (K^-1 (u, v, 1) d) + c  (inverse_warp.py:253-260)
+    const T Y = (qcy + qvy * vf) * d + c1;
+    const T Zraw = (qcz + qvz * vf) * d + c2;
     const T Z = t_max(Zraw, T(kZMin));            // inverse_warp.py:211
     const T iz = t_rcp(Z);
     const T xn = (X * iz) * inv_w - T(1);         // inverse_warp.py:217-218
@@ -167,8 +167,8 @@ struct StripUnit {
     // is a tap: the east one), (0, -1) right of it; likewise for the rows
     const T Lx = ta < T(0) ? T(1) : T(0), Rx = tb >= T(0) ? T(1) : T(0);
     const T Ly = sa < T(0) ? T(1) : T(0), Ry = sb >= T(0) ? T(1) : T(0);
-    const T dxa = T(2) * Lx + Rx - T(1), dxb = T(1) - Lx - T(2) * Rx;
-    const T dya = T(2) * Ly + Ry - T(1), dyb = T(1) - Ly - T(2) * Ry;
+    const T dxa = (T(2) * Lx + Rx - T(1)) * kx, dxb = (T(1) - Lx - T(2) * Rx) * kx;  // (times d ix / d (X/Z))
+    const T dya = (T(2) * Ly + Ry - T(1)) * ky, dyb = (T(1) - Ly - T(2) * Ry) * ky;
     const int xa = int(fxa), ya = int(fya);
     const unsigned off = (unsigned(ya) * unsigned(W) + unsigned(xa)) * unsigned(sizeof(T));
     const unsigned off_s = off + unsigned(W) * unsigned(sizeof(T));
@@ -216,7 +216,8 @@ struct StripUnit {
     const T dd = clamp01(raw);                     // loss_functions.py:101
     const bool ddpass = raw >= T(0) && raw <= T(1);
     const T g2 = ddpass ? t_sgn(diff) * T(2) * isum * isum : T(0);
-    rw.gZc = g2 * Dp;
+    const T zg = Zraw >= T(kZMin) ? T(1) : T(0);   // Z = clamp(Zraw, min = 1e-3) passes gradient where Zraw >= 1e-3
+    rw.gZc = g2 * Dp * zg;
     rw.gDpc = -g2 * Z;
     T m = (valid && inimg) ? T(1) : T(0);
     if (with_auto) m = (l1 < ident) ? m : T(0);    // loss_functions.py:103-105 (both means share the divisor 3)
@@ -225,8 +226,8 @@ struct StripUnit {
     rw.coef = with_mask ? m * (T(1) - dd) : m;     // loss_functions.py:111-113
     rw.wxa = wxa; rw.wxb = wxb; rw.wya = wya; rw.wyb = wyb;
     rw.tap = (unsigned(ya) << 16) | unsigned(xa);
-    rw.X = X; rw.Y = Y; rw.iz = iz; rw.d = d;
-    rw.kx = kx; rw.ky = ky; rw.zg = Zraw >= T(kZMin) ? T(1) : T(0);
+    const T zq = zg * iz * iz;
+    rw.Xz = X * zq; rw.Yz = Y * zq; rw.iz = iz; rw.d = d;
     if (own_x && t >= r0 && t < r1) { acc_g += dd * m; acc_m += m; }
   }
 
@@ -313,21 +314,20 @@ struct StripUnit {
     const T gix = gI[0] * rp.dIx[0] + gI[1] * rp.dIx[1] + gI[2] * rp.dIx[2] + gDp * rp.dDx;
     const T giy = gI[0] * rp.dIy[0] + gI[1] * rp.dIy[1] + gI[2] * rp.dIy[2] + gDp * rp.dDy;
     scatter(rp, gDp);
-    // ix = ((xn+1) W - 1)/2, xn = 2 (X/Z)/(W-1) - 1; Z = clamp(Zraw, min=1e-3) passes gradient where Zraw >= 1e-3
-    const T gqx = gix * rp.kx, gqy = giy * rp.ky;
-    const T dX = gqx * rp.iz, dY = gqy * rp.iz;
-    const T dZ = rp.zg * (gZ - (gqx * rp.X + gqy * rp.Y) * rp.iz * rp.iz);
+    // gix, giy are already gradients with respect to X/Z, Y/Z (the factors of ix = ((xn+1) W - 1)/2,
+    // xn = 2 (X/Z)/(W-1) - 1 and the overwrite / clip gates were folded into the stored derivatives)
+    const T dX = gix * rp.iz, dY = giy * rp.iz;
+    const T dZ = gZ - (gix * rp.Xz + giy * rp.Yz);
+    // dL/d(A K^-1) accumulated against d (u, v, 1) (turned into dL/dA in the unit's epilogue); dL/dc
     const T vf = T(p);
-    const T rx = kx0 + bc.Kinv[1] * vf, ry = ky0 + bc.Kinv[4] * vf, rz = kz0 + bc.Kinv[7] * vf;
-    const T cx = rx * rp.d, cy = ry * rp.d, cz = rz * rp.d;
-    acc[0] += dX * cx; acc[1] += dX * cy; acc[2] += dX * cz;
-    acc[3] += dY * cx; acc[4] += dY * cy; acc[5] += dY * cz;
-    acc[6] += dZ * cx; acc[7] += dZ * cy; acc[8] += dZ * cz;
+    const T tX = dX * rp.d, tY = dY * rp.d, tZ = dZ * rp.d;
+    acc[0] += tX * uf; acc[1] += tX * vf; acc[2] += tX;
+    acc[3] += tY * uf; acc[4] += tY * vf; acc[5] += tY;
+    acc[6] += tZ * uf; acc[7] += tZ * vf; acc[8] += tZ;
     acc[9] += dX; acc[10] += dY; acc[11] += dZ;
-    const T gcx = bc.A[0] * dX + bc.A[3] * dY + bc.A[6] * dZ;
-    const T gcy = bc.A[1] * dX + bc.A[4] * dY + bc.A[7] * dZ;
-    const T gcz = bc.A[2] * dX + bc.A[5] * dY + bc.A[8] * dZ;
-    st_at(g_dense, (unsigned(p) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), rx * gcx + ry * gcy + rz * gcz);
+    // dL/d depth = <d(X, Y, Z')/d depth, (dX, dY, dZ)> = <q, .>
+    const T gd = (qcx + qvx * vf) * dX + (qcy + qvy * vf) * dY + (qcz + qvz * vf) * dZ;
+    st_at(g_dense, (unsigned(p) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gd);
   }
 
   // step k: warp row t = r0 - 2 + k (slot S), statistics of row t - 1, output of row t - 2
@@ -379,16 +379,27 @@ __device__ __forceinline__ void strip_unit(const PairArgs<T>& pa, int b, int seg
   s.ref_depth = pa.ref_depth + (size_t)b * s.plane;
   s.g_dense = pa.gbuf + kPlaneDense * gplane + (size_t)b * s.plane;
   s.g_scatter = pa.gbuf + kPlaneScatter * gplane + (size_t)b * s.plane;
-  s.bc = pa.consts[b];
   s.r0 = seg * kStripRows;
   s.r1 = s.r0 + kStripRows < H ? s.r0 + kStripRows : H;
   s.px = strip * kStripOut - 2 + s.lane;
   s.u = reflect_index(s.px, W);
   s.col_in = s.px >= 0 && s.px < W;
   s.own_x = s.lane >= 2 && s.lane <= kWave - 3 && s.px < W;
-  const T uf = T(s.u);
-  // K^-1 (u, v, 1): the column part once per lane
-  s.kx0 = s.bc.Kinv[0] * uf + s.bc.Kinv[2]; s.ky0 = s.bc.Kinv[3] * uf + s.bc.Kinv[5]; s.kz0 = s.bc.Kinv[6] * uf + s.bc.Kinv[8];
+  s.uf = T(s.u);
+  {
+    // M = A K^-1 (wave-uniform; evaluated once per unit): X = (M (u, v, 1)) d + c
+    const BatchConsts<T>& bc = pa.consts[b];
+    T M[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) M[3 * i + j] = bc.A[3 * i] * bc.Kinv[j] + bc.A[3 * i + 1] * bc.Kinv[3 + j] + bc.A[3 * i + 2] * bc.Kinv[6 + j];
+    s.qcx = M[0] * s.uf + M[2]; s.qcy = M[3] * s.uf + M[5]; s.qcz = M[6] * s.uf + M[8];
+    s.qvx = M[1]; s.qvy = M[4]; s.qvz = M[7];
+    s.c0 = bc.c[0]; s.c1 = bc.c[1]; s.c2 = bc.c[2];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s.Kinv[i] = bc.Kinv[i];
+  }
   s.inv_w = T(2) / T(W - 1); s.inv_h = T(2) / T(H - 1);
   // transpose of (reflect pad o box): an output next to the image border is reached twice from the border pixel
   s.wl = reflect_mult<T>(-1, s.px, W); s.wr = reflect_mult<T>(1, s.px, W);
@@ -426,9 +437,17 @@ __device__ __forceinline__ void strip_unit(const PairArgs<T>& pa, int b, int seg
     if (lead) pa.partials[3 * unit + idx] = double(v[0]);
   }
   {
+    // dL/dA[i][j] = sum_k G[i][k] K^-1[j][k]  (cam = K^-1 (u, v, 1) d, G accumulated against d (u, v, 1))
+    T gA[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        gA[3 * i + j] = s.acc[3 * i] * s.Kinv[3 * j] + s.acc[3 * i + 1] * s.Kinv[3 * j + 1] + s.acc[3 * i + 2] * s.Kinv[3 * j + 2];
+    gA[9] = s.acc[9]; gA[10] = s.acc[10]; gA[11] = s.acc[11];
     bool lead;
-    const int idx = wave_sum_packed<12>(s.acc, lead);
-    if (lead) pa.gPp[12 * unit + idx] = double(s.acc[0]);
+    const int idx = wave_sum_packed<12>(gA, lead);
+    if (lead) pa.gPp[12 * unit + idx] = double(gA[0]);
   }
 }
 
