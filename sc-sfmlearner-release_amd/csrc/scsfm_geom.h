@@ -159,29 +159,52 @@ __device__ __forceinline__ void pose_reduce_one(int b, int nblk, double scale, c
 
 // ------------------------------------------------------------------------------------------
 // One target pixel -> where it lands in the reference view.
+//
+// Bilinear sampling (ATen grid_sampler_2d, bilinear, align_corners=False, zeros | border) is evaluated on a 2 x 2
+// block of pixels that always lies INSIDE the image -- columns xa, xa + 1 with xa = clamp(floor(ix), 0, W - 2), rows
+// ya, ya + 1 likewise -- with the hat function max(0, 1 - |ix - column|) as the weight of a column.  For a column
+// of the block that is a tap this is exactly the bilinear weight; for one that is not (the sampling position lies
+// left of column 0, right of column W - 1, ...) it is 0, and every tap outside the image -- which contributes 0 under
+// zeros padding -- is simply never addressed.  No bounds test, no predicated load, no select: the weights cost two
+// subtractions with |.| / clamp modifiers each (full-rate VALU on gfx950, where compares, selects and min / max run at
+// half rate: tools/ubench).
 // ------------------------------------------------------------------------------------------
 template <typename T>
 struct Sample {
   T rx, ry, rz;     // K^-1 (u, v, 1)
   T X, Y, Zraw, Z;  // A cam + c ; Z = max(Zraw, 1e-3) is the "computed depth"
-  T fx, fy;         // bilinear fractions (distance to the west / north tap)
   T gmx, gmy;       // d ix / d xn (= W/2), zeroed by the zeros-mode overwrite or the border clip
-  T w[4];           // bilinear weights of the taps (0 nw, 1 ne, 2 sw, 3 se); 0 for taps outside the image
-  unsigned off[4];  // element offset of each tap inside a plane, clamped into the image so that the
-                    // four loads need no predication (their weight is 0 when they were clamped)
-  unsigned offr[2]; // element offset of the (west, east) tap PAIR of the north / south row: the west column is
-                    // clamped to [0, W-2] so that one 8-byte load fetches both taps of a row
-  int xsel;         // x0 - clamped west column: -1 / 0 / +1 tells which half of the pair is which tap
-  T wp[4];          // the bilinear weights re-addressed to the loaded pairs (north.a, north.b, south.a, south.b):
-                    // equal to w[] except where the pair was shifted at the left / right image border
-  T wxa, wxb;       // ... their column factors (weight of the pair's first / second element)
-  T wy0, wy1;       // ... and row factors (north / south row; 0 for a row outside the image)
-  T sxa, sxb;       // d(column weight)/d ix of the pair's elements: -1 / +1 for a tap inside the image, else 0
-  T vy0, vy1;       // 1 if the north / south row lies inside the image
-  unsigned inb;     // bit k: tap k lies inside the image
-  int x0, y0;       // north-west tap (unclamped)
+  int xa, ya;       // first column / row of the 2 x 2 block
+  unsigned offr[2]; // element offset of (ya, xa) and (ya + 1, xa) inside a plane: one 8-byte load per row fetches a pair
+  T wxa, wxb;       // weights of the block's columns ...
+  T wya, wyb;       // ... and rows
+  T wp[4];          // their products: weights of (n.a, n.b, s.a, s.b)
+  T sxa, sxb;       // d (column weight) / d ix: (-1, +1) between the columns, (+1, 0) left of the image, (0, -1) right of it
+  T sya, syb;       // d (row weight) / d iy
   bool valid;       // max(|xn|, |yn|) <= 1   (inverse_warp.py:264)
 };
+
+__device__ __forceinline__ float t_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ double t_med3(double x, double lo, double hi) { return t_min(t_max(x, lo), hi); }
+
+template <typename T>
+__device__ __forceinline__ T clamp01_(T x) { return t_min(t_max(x, T(0)), T(1)); }
+
+// The block and its weights along one axis: coordinate `ix` (already overwritten / clipped), image extent n.
+template <typename T>
+__device__ __forceinline__ void hat_axis(T ix, int n, int& ia, T& wa, T& wb, T& sa, T& sb) {
+  const T f0 = t_floor(ix);
+  const T fa = t_med3(f0, T(0), T(n - 2));  // (NaN-safe: med3 of a NaN returns a bound)
+  const T ta = ix - fa, tb = ta - T(1);
+  wa = clamp01_(T(1) - t_abs(ta));
+  wb = clamp01_(T(1) - t_abs(tb));
+  // the position lies before (floor(ix) = -1 < first column) / beyond (floor(ix) > first column) the block: both
+  // differences are small integers, so the clamp is an exact 0 / 1 indicator (ix >= -1 by construction)
+  const T L = clamp01_(fa - f0), R = clamp01_(f0 - fa);
+  sa = T(2) * L + R - T(1);
+  sb = T(1) - L - T(2) * R;
+  ia = int(fa);
+}
 
 template <typename T>
 __device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int u, int v, T depth,
@@ -202,61 +225,38 @@ __device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int
   // xn = 2 (X/Z)/(W-1) - 1 (inverse_warp.py:217-218); the two divisions are a reciprocal of Z and a
   // per-launch constant (1-2 ulp from the reference's correctly rounded quotients)
   const T iz = t_rcp(s.Z);
-  T xn = (s.X * iz) * (T(2) / T(W - 1)) - T(1);
-  T yn = (s.Y * iz) * (T(2) / T(H - 1)) - T(1);
+  const T xn = (s.X * iz) * (T(2) / T(W - 1)) - T(1);
+  const T yn = (s.Y * iz) * (T(2) / T(H - 1)) - T(1);
   s.gmx = T(0.5) * T(W);
   s.gmy = T(0.5) * T(H);
-  if (overwrite) {  // inverse_warp.py:219-224: out-of-range coordinates become the constant 2
-    if (xn > T(1) || xn < T(-1)) { xn = T(2); s.gmx = T(0); }
-    if (yn > T(1) || yn < T(-1)) { yn = T(2); s.gmy = T(0); }
-  }
-  s.valid = t_max(t_abs(xn), t_abs(yn)) <= T(1);
+  const bool vx = t_abs(xn) <= T(1), vy = t_abs(yn) <= T(1);  // (false for NaN)
+  s.valid = vx && vy;
   // grid_sampler_unnormalize, align_corners=False
   T ix = ((xn + T(1)) * T(W) - T(1)) * T(0.5);
   T iy = ((yn + T(1)) * T(H) - T(1)) * T(0.5);
-  if (border) {  // clip_coordinates_set_grad: zero gradient on and outside the bounds
+  if (overwrite) {
+    // inverse_warp.py:219-224: out-of-range coordinates become the constant 2, a sampling position all of whose taps
+    // lie outside the image -- like -1 (weight 1 on column -1, weight 0 on column 0), which keeps the block at the
+    // image corner
+    if (!vx) { ix = T(-1); s.gmx = T(0); }
+    if (!vy) { iy = T(-1); s.gmy = T(0); }
+  } else if (border) {  // clip_coordinates_set_grad: zero gradient on and outside the bounds
     if (!(ix > T(0))) { ix = T(0); s.gmx = T(0); } else if (!(ix < T(W - 1))) { ix = T(W - 1); s.gmx = T(0); }
     if (!(iy > T(0))) { iy = T(0); s.gmy = T(0); } else if (!(iy < T(H - 1))) { iy = T(H - 1); s.gmy = T(0); }
-  } else {  // keep the float->int conversion defined for NaN / huge coordinates
-    if (!(ix >= T(-2) && ix <= T(W + 1))) ix = T(-2);
-    if (!(iy >= T(-2) && iy <= T(H + 1))) iy = T(-2);
+  } else {
+    // legacy grid, zeros padding, any coordinate: positions beyond [-1, W] sample nothing, exactly like -1 and W
+    ix = t_med3(ix, T(-1), T(W));
+    iy = t_med3(iy, T(-1), T(H));
   }
-  const T fx0 = t_floor(ix), fy0 = t_floor(iy);
-  s.fx = ix - fx0;
-  s.fy = iy - fy0;
-  const int x0 = int(fx0), y0 = int(fy0), x1 = x0 + 1, y1 = y0 + 1;
-  s.x0 = x0; s.y0 = y0;
-  const bool xw = x0 >= 0 && x0 < W, xe = x1 >= 0 && x1 < W;
-  const bool yn_ = y0 >= 0 && y0 < H, ys = y1 >= 0 && y1 < H;
-  s.inb = (xw && yn_ ? 1u : 0u) | (xe && yn_ ? 2u : 0u) | (xw && ys ? 4u : 0u) | (xe && ys ? 8u : 0u);
-  // ATen CPU kernel: nw = s*e, ne = s*w, sw = n*e, se = n*w with w = fx, e = 1-fx, n = fy, s = 1-fy
-  const T e = T(1) - s.fx, so = T(1) - s.fy;
-  const T wx0 = xw ? e : T(0), wx1 = xe ? s.fx : T(0), wy0 = yn_ ? so : T(0), wy1 = ys ? s.fy : T(0);
-  s.w[0] = wy0 * wx0; s.w[1] = wy0 * wx1; s.w[2] = wy1 * wx0; s.w[3] = wy1 * wx1;
-  const int xc0 = t_clampi(x0, 0, W - 1), xc1 = t_clampi(x1, 0, W - 1);
-  const int r0 = t_clampi(y0, 0, H - 1) * W, r1 = t_clampi(y1, 0, H - 1) * W;
-  s.off[0] = unsigned(r0 + xc0); s.off[1] = unsigned(r0 + xc1);
-  s.off[2] = unsigned(r1 + xc0); s.off[3] = unsigned(r1 + xc1);
-  const int xa = t_clampi(x0, 0, W - 2);
-  s.offr[0] = unsigned(r0 + xa); s.offr[1] = unsigned(r1 + xa);
-  s.xsel = x0 - xa;
-  // xsel = -1: the pair is (I[0], I[1]) and only its first half is a tap (the east one); xsel = +1: the
-  // pair is (I[W-2], I[W-1]) and only its second half is a tap (the west one)
-  const T mw = xw ? T(-1) : T(0), me = xe ? T(1) : T(0);
-  s.wxa = s.xsel == 1 ? T(0) : (s.xsel == -1 ? wx1 : wx0);
-  s.wxb = s.xsel == -1 ? T(0) : (s.xsel == 1 ? wx0 : wx1);
-  s.sxa = s.xsel == 1 ? T(0) : (s.xsel == -1 ? me : mw);
-  s.sxb = s.xsel == -1 ? T(0) : (s.xsel == 1 ? mw : me);
-  s.wy0 = wy0; s.wy1 = wy1;
-  s.vy0 = yn_ ? T(1) : T(0); s.vy1 = ys ? T(1) : T(0);
-  s.wp[0] = wy0 * s.wxa; s.wp[1] = wy0 * s.wxb; s.wp[2] = wy1 * s.wxa; s.wp[3] = wy1 * s.wxb;
+  hat_axis(ix, W, s.xa, s.wxa, s.wxb, s.sxa, s.sxb);
+  hat_axis(iy, H, s.ya, s.wya, s.wyb, s.sya, s.syb);
+  s.offr[0] = unsigned(s.ya) * unsigned(W) + unsigned(s.xa);
+  s.offr[1] = s.offr[0] + unsigned(W);
+  s.wp[0] = s.wya * s.wxa; s.wp[1] = s.wya * s.wxb; s.wp[2] = s.wyb * s.wxa; s.wp[3] = s.wyb * s.wxb;
   return s;
 }
 
-// The four taps of one plane.  Unpredicated, two 8-byte loads (global_load_dwordx2 needs only dword
-// alignment): each row's pair starts at a west column clamped to [0, W-2]; when the sampling position
-// straddles the left / right image border (xsel = -1 / +1) the in-image tap sits in the other half of
-// the pair and the out-of-image tap has weight 0 whatever it reads.
+// The 2 x 2 block of one plane: two 8-byte loads (global_load_dwordx2 needs only dword alignment), unpredicated.
 template <typename T>
 struct TapPair { T a, b; };
 template <typename T>
@@ -268,51 +268,18 @@ __device__ __forceinline__ TapRows<T> load_tap_rows(const T* __restrict__ plane,
   r.s = ld_at(reinterpret_cast<const TapPair<T>*>(plane), s.offr[1] * unsigned(sizeof(T)));
   return r;
 }
-// The sampled value straight from the pairs (no re-ordering of the data: the weights were re-addressed).
+// The sampled value.
 template <typename T>
 __device__ __forceinline__ T bilerp_rows(const TapRows<T>& r, const Sample<T>& s) {
   return r.n.a * s.wp[0] + r.n.b * s.wp[1] + r.s.a * s.wp[2] + r.s.b * s.wp[3];
 }
-// d(sampled value)/d(ix, iy) from the pairs: out-of-image taps count as the value 0 and have no weight
-// (what grid_sampler_2d_backward does for the coordinate gradient).
-//   d/d ix = sum_rows wy * (east - west),  d/d iy = sum_cols wx * (south - north)
+// d(sampled value)/d(ix, iy): out-of-image taps count as the value 0 and have no weight (what
+// grid_sampler_2d_backward does for the coordinate gradient) -- the slopes of the hat weights.
 template <typename T>
 __device__ __forceinline__ void tap_rows_grad(const TapRows<T>& r, const Sample<T>& s, T& dx, T& dy) {
-  dx = s.wy0 * (s.sxa * r.n.a + s.sxb * r.n.b) + s.wy1 * (s.sxa * r.s.a + s.sxb * r.s.b);
-  dy = s.vy1 * (s.wxa * r.s.a + s.wxb * r.s.b) - s.vy0 * (s.wxa * r.n.a + s.wxb * r.n.b);
+  dx = s.wya * (s.sxa * r.n.a + s.sxb * r.n.b) + s.wyb * (s.sxa * r.s.a + s.sxb * r.s.b);
+  dy = s.sya * (s.wxa * r.n.a + s.wxb * r.n.b) + s.syb * (s.wxa * r.s.a + s.wxb * r.s.b);
 }
-// The four taps in tap order (the backward needs the values themselves).
-template <typename T>
-__device__ __forceinline__ void load_taps(const T* __restrict__ plane, const Sample<T>& s, T* v) {
-  const TapRows<T> r = load_tap_rows(plane, s);
-  const TapPair<T> n = r.n, so = r.s;
-  v[0] = s.xsel == 1 ? n.b : n.a;  v[1] = s.xsel == -1 ? n.a : n.b;
-  v[2] = s.xsel == 1 ? so.b : so.a; v[3] = s.xsel == -1 ? so.a : so.b;
-}
-
-template <typename T>
-__device__ __forceinline__ T bilerp(const T* v, const Sample<T>& s) {
-  return v[0] * s.w[0] + v[1] * s.w[1] + v[2] * s.w[2] + v[3] * s.w[3];
-}
-
-// d(sample)/d(ix, iy): out-of-image taps count as the value 0 (what grid_sampler_2d_backward does for
-// the coordinate gradient), so the loaded (clamped) values are masked first.
-template <typename T>
-struct SampleGrad {
-  T cx[4], cy[4];
-};
-template <typename T>
-__device__ __forceinline__ SampleGrad<T> sample_grad(const Sample<T>& s) {
-  SampleGrad<T> g;
-  const T m0 = (s.inb & 1u) ? T(1) : T(0), m1 = (s.inb & 2u) ? T(1) : T(0);
-  const T m2 = (s.inb & 4u) ? T(1) : T(0), m3 = (s.inb & 8u) ? T(1) : T(0);
-  const T e = T(1) - s.fx, so = T(1) - s.fy;
-  g.cx[0] = -so * m0; g.cx[1] = so * m1; g.cx[2] = -s.fy * m2; g.cx[3] = s.fy * m3;
-  g.cy[0] = -e * m0; g.cy[1] = -s.fx * m1; g.cy[2] = e * m2; g.cy[3] = s.fx * m3;
-  return g;
-}
-template <typename T>
-__device__ __forceinline__ T dot4(const T* v, const T* c) { return v[0] * c[0] + v[1] * c[1] + v[2] * c[2] + v[3] * c[3]; }
 
 // Gradient of one pixel's sampling position back to the target depth and to A|c.
 //   gix, giy : dL/d(ix, iy) (un-normalised sampling coordinates)
@@ -345,10 +312,11 @@ __device__ __forceinline__ T pixel_geometry_bwd(const BatchConsts<T>& bc, const 
 template <typename T>
 __device__ __forceinline__ void scatter_taps(T* __restrict__ gplane, const Sample<T>& s, T g) {
   if (g == T(0)) return;
-  if (s.inb & 1u) atomicAdd(gplane + s.off[0], g * s.w[0]);
-  if (s.inb & 2u) atomicAdd(gplane + s.off[1], g * s.w[1]);
-  if (s.inb & 4u) atomicAdd(gplane + s.off[2], g * s.w[2]);
-  if (s.inb & 8u) atomicAdd(gplane + s.off[3], g * s.w[3]);
+  // (a cell of the block that is not a tap has weight 0)
+  if (s.wp[0] != T(0)) atomicAdd(gplane + s.offr[0], g * s.wp[0]);
+  if (s.wp[1] != T(0)) atomicAdd(gplane + s.offr[0] + 1, g * s.wp[1]);
+  if (s.wp[2] != T(0)) atomicAdd(gplane + s.offr[1], g * s.wp[2]);
+  if (s.wp[3] != T(0)) atomicAdd(gplane + s.offr[1] + 1, g * s.wp[3]);
 }
 
 
@@ -392,13 +360,13 @@ template <typename T, typename Cell, int WW, int WH>
 __device__ __forceinline__ void scatter_taps_window(Cell (*win)[WW], int wx0, int wy0,
                                                     T* __restrict__ gplane, const Sample<T>& s, T g) {
   if (g == T(0)) return;
-  const int lx = s.x0 - wx0, ly = s.y0 - wy0;
+  const int lx = s.xa - wx0, ly = s.ya - wy0;
   if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < WH - 1) {
-    // unpredicated: an out-of-image tap has weight 0, and adding 0 leaves its cell at the 0 the flush skips
-    win_add(&win[ly][lx], g * s.w[0]);
-    win_add(&win[ly][lx + 1], g * s.w[1]);
-    win_add(&win[ly + 1][lx], g * s.w[2]);
-    win_add(&win[ly + 1][lx + 1], g * s.w[3]);
+    // unpredicated: a cell of the block that is not a tap has weight 0, and adding 0 leaves it at the 0 the flush skips
+    win_add(&win[ly][lx], g * s.wp[0]);
+    win_add(&win[ly][lx + 1], g * s.wp[1]);
+    win_add(&win[ly + 1][lx], g * s.wp[2]);
+    win_add(&win[ly + 1][lx + 1], g * s.wp[3]);
   } else {
     scatter_taps(gplane, s, g);
   }
@@ -442,8 +410,8 @@ __device__ __forceinline__ void window_origin(const BatchConsts<T>& bc, int ax, 
                                               int H, int W, unsigned flags, int& wx0, int& wy0) {
   ax = t_clampi(ax, 0, W - 1); ay = t_clampi(ay, 0, H - 1);
   const Sample<T> sc = project_pixel(bc, ax, ay, tgt_depth[unsigned(ay) * unsigned(W) + unsigned(ax)], H, W, flags);
-  wx0 = sc.x0 - WW / 2;
-  wy0 = sc.y0 - WH / 2;
+  wx0 = sc.xa - WW / 2;
+  wy0 = sc.ya - WH / 2;
 }
 
 // Backward of one target pixel through the bilinear sampler and the camera geometry (the per-pixel body of

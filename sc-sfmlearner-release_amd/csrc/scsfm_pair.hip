@@ -442,8 +442,8 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
       if (in_x && ly >= 1 && ly <= TH - 2 && py < H) {
         acc_g += ddk * mq[k]; acc_m += mq[k];
         if (mq[k] != T(0)) {  // this pixel will scatter: where its north-west tap lies
-          bx0 = s.x0 < bx0 ? s.x0 : bx0; bx1 = s.x0 > bx1 ? s.x0 : bx1;
-          by0 = s.y0 < by0 ? s.y0 : by0; by1 = s.y0 > by1 ? s.y0 : by1;
+          bx0 = s.xa < bx0 ? s.xa : bx0; bx1 = s.xa > bx1 ? s.xa : bx1;
+          by0 = s.ya < by0 ? s.ya : by0; by1 = s.ya > by1 ? s.ya : by1;
         }
       }
     }

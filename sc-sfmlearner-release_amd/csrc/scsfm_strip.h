@@ -68,9 +68,6 @@ __device__ __forceinline__ double lane_right(double v) {
 }
 template <typename T> __device__ __forceinline__ T box3(T v) { return (v + lane_left(v)) + lane_right(v); }
 
-__device__ __forceinline__ float t_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
-__device__ __forceinline__ double t_med3(double x, double lo, double hi) { return t_min(t_max(x, lo), hi); }
-
 // ------------------------------------------------------------------------------------------------------
 // What a lane keeps of one row: the pixel it warped there.
 // ------------------------------------------------------------------------------------------------------
@@ -158,18 +155,13 @@ struct StripUnit {
       if (!(ix > T(0))) { ix = T(0); kx = T(0); } else if (!(ix < T(W - 1))) { ix = T(W - 1); kx = T(0); }
       if (!(iy > T(0))) { iy = T(0); ky = T(0); } else if (!(iy < T(H - 1))) { iy = T(H - 1); ky = T(0); }
     }
-    // tap pair (xa, xa + 1) x (ya, ya + 1), always inside the image; hat-function weights
-    const T fxa = t_med3(t_floor(ix), T(0), T(W - 2)), fya = t_med3(t_floor(iy), T(0), T(H - 2));
-    const T ta = ix - fxa, tb = ta - T(1), sa = iy - fya, sb = sa - T(1);
-    const T wxa = clamp01(T(1) - t_abs(ta)), wxb = clamp01(T(1) - t_abs(tb));
-    const T wya = clamp01(T(1) - t_abs(sa)), wyb = clamp01(T(1) - t_abs(sb));
-    // d weight / d coordinate of the pair's columns: (-1, +1) between them, (+1, 0) left of the image (only column 0
-    // is a tap: the east one), (0, -1) right of it; likewise for the rows
-    const T Lx = ta < T(0) ? T(1) : T(0), Rx = tb >= T(0) ? T(1) : T(0);
-    const T Ly = sa < T(0) ? T(1) : T(0), Ry = sb >= T(0) ? T(1) : T(0);
-    const T dxa = (T(2) * Lx + Rx - T(1)) * kx, dxb = (T(1) - Lx - T(2) * Rx) * kx;  // (times d ix / d (X/Z))
-    const T dya = (T(2) * Ly + Ry - T(1)) * ky, dyb = (T(1) - Ly - T(2) * Ry) * ky;
-    const int xa = int(fxa), ya = int(fya);
+    // tap block (xa, xa + 1) x (ya, ya + 1), always inside the image; hat-function weights and their slopes
+    // (scsfm_geom.h: hat_axis), the slopes times d ix / d (X/Z)
+    int xa, ya;
+    T wxa, wxb, wya, wyb, dxa, dxb, dya, dyb;
+    hat_axis(ix, W, xa, wxa, wxb, dxa, dxb);
+    hat_axis(iy, H, ya, wya, wyb, dya, dyb);
+    dxa *= kx; dxb *= kx; dya *= ky; dyb *= ky;
     const unsigned off = (unsigned(ya) * unsigned(W) + unsigned(xa)) * unsigned(sizeof(T));
     const unsigned off_s = off + unsigned(W) * unsigned(sizeof(T));
     TapRows<T> tc[3], td;

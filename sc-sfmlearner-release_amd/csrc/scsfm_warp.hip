@@ -19,14 +19,9 @@ __global__ __launch_bounds__(kThreads) void warp_fwd_kernel(
   const BatchConsts<T> bc = consts[b];
   const long plane = (long)H * W, p = (long)v * W + u;
   const Sample<T> s = project_pixel(bc, u, v, depth[b * plane + p], H, W, flags);
-  T t[4];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    load_taps(img + (b * 3 + c) * plane, s, t);
-    out_img[(b * 3 + c) * plane + p] = bilerp(t, s);
-  }
-  load_taps(ref_depth + b * plane, s, t);
-  out_pdepth[b * plane + p] = bilerp(t, s);
+  for (int c = 0; c < 3; ++c) out_img[(b * 3 + c) * plane + p] = bilerp_rows(load_tap_rows(img + (b * 3 + c) * plane, s), s);
+  out_pdepth[b * plane + p] = bilerp_rows(load_tap_rows(ref_depth + b * plane, s), s);
   out_valid[b * plane + p] = s.valid ? T(1) : T(0);
   out_cdepth[b * plane + p] = s.Z;
 }
@@ -49,22 +44,21 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(
   if (u < W && v < H) {
     const T d = depth[b * plane + p];
     const Sample<T> s = project_pixel(bc, u, v, d, H, W, flags);
-    const SampleGrad<T> sg = sample_grad(s);
-    T gix = T(0), giy = T(0), t[4];
+    T gix = T(0), giy = T(0), dx, dy;
     if (g_img) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        load_taps(img + (b * 3 + c) * plane, s, t);
+        tap_rows_grad(load_tap_rows(img + (b * 3 + c) * plane, s), s, dx, dy);
         const T g = g_img[(b * 3 + c) * plane + p];
-        gix += g * dot4(t, sg.cx);
-        giy += g * dot4(t, sg.cy);
+        gix += g * dx;
+        giy += g * dy;
       }
     }
     if (g_pdepth) {
-      load_taps(ref_depth + b * plane, s, t);
+      tap_rows_grad(load_tap_rows(ref_depth + b * plane, s), s, dx, dy);
       const T g = g_pdepth[b * plane + p];
-      gix += g * dot4(t, sg.cx);
-      giy += g * dot4(t, sg.cy);
+      gix += g * dx;
+      giy += g * dy;
       scatter_taps(g_ref_depth + b * plane, s, g);
     }
     const T gZ = g_cdepth ? g_cdepth[b * plane + p] : T(0);
