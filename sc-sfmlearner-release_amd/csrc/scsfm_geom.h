@@ -427,16 +427,11 @@ __device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py
                                         unsigned plane, int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
                                         T* __restrict__ scatter_plane, T* acc) {
   const Sample<T> s = project_pixel(bc, px, py, d, H, W, flags);
-  T gix = T(0), giy = T(0), dx, dy;
+  TapRows<T> tc[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    tap_rows_grad(load_tap_rows(ref_img + c * plane, s), s, dx, dy);
-    gix += gI[c] * dx; giy += gI[c] * dy;
-  }
+  for (int c = 0; c < 3; ++c) tc[c] = load_tap_rows(ref_img + c * plane, s);
   const TapRows<T> td = load_tap_rows(ref_depth, s);
   const T Dp = bilerp_rows(td, s);
-  T dDx, dDy;
-  tap_rows_grad(td, s, dDx, dDy);
   const T diff = s.Z - Dp, sum = s.Z + Dp;
   const T isum = t_rcp(sum);
   const T raw = t_abs(diff) * isum;
@@ -446,8 +441,15 @@ __device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py
     gZ = g_dd * (sgn * T(2) * Dp * i2);
     gDp = -g_dd * (sgn * T(2) * s.Z * i2);
   }
-  gix += gDp * dDx;
-  giy += gDp * dDy;
+  // d (sum over the four planes of g_plane * sampled value) / d (ix, iy): contract over the planes first (g = dL/d
+  // warped colour c, dL/dD_p), then apply the block's weights and slopes once -- 28 operations instead of 56
+  TapRows<T> t;
+  t.n.a = gI[0] * tc[0].n.a + gI[1] * tc[1].n.a + gI[2] * tc[2].n.a + gDp * td.n.a;
+  t.n.b = gI[0] * tc[0].n.b + gI[1] * tc[1].n.b + gI[2] * tc[2].n.b + gDp * td.n.b;
+  t.s.a = gI[0] * tc[0].s.a + gI[1] * tc[1].s.a + gI[2] * tc[2].s.a + gDp * td.s.a;
+  t.s.b = gI[0] * tc[0].s.b + gI[1] * tc[1].s.b + gI[2] * tc[2].s.b + gDp * td.s.b;
+  T gix, giy;
+  tap_rows_grad(t, s, gix, giy);
   if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, Cell, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp);
   return pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
 }

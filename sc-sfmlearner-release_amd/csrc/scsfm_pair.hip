@@ -242,7 +242,7 @@ __device__ __forceinline__ void publish_losses(double Sp, double Sg, double Sm, 
 // `total` (optional): the sums over all pair-directions of a call of the two losses -- what
 // compute_photo_and_geometry_loss returns -- finished by whichever block comes last, in pair order.
 template <typename T>
-__global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb, int nblocks, double spec,
+__global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb, int nblocks, int nblk_img, double spec,
                                                                  double w_photo, double w_geom, T* total, int first) {
   __shared__ double red[3 * (kThreads / kWave)];
   const PairArgs<T>& pa = pb.p[blockIdx.x];
@@ -257,6 +257,7 @@ __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb
   if (threadIdx.x == 0) {
     publish_losses(v[0], v[1], v[2], sums, out);
     sums[8] = spec; sums[9] = w_photo; sums[10] = w_geom;
+    sums[11] = double(nblk_img);  // partial records per image the forward left (the pose reduction of the backward reads them)
     if (total) {
       __threadfence();
       if (atomicAdd(finalize_counter(pb), 1u) == gridDim.x - 1) {
@@ -480,7 +481,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
         const SsimStats<T> st = ssim_stats(ws[k]);
         bsum[k] += T(0.85) * clamp01(st.raw);
         // s = clamp((1 - S)/2, 0, 1): d s / d S = -1/2 inside the clamp (inclusive bounds)
-        const T gS = (st.raw >= T(0) && st.raw <= T(1)) ? coef[k] * T(0.85) * T(-0.5) : T(0);
+        const T gS = clamp01(st.raw) == st.raw ? coef[k] * T(0.85) * T(-0.5) : T(0);  // (i.e. 0 <= raw <= 1)
         T g1, g2, g3;
         ssim_grad_y(st, gS, g1, g2, g3);
         const int ly = strip * STRIP + k;
@@ -766,12 +767,12 @@ __device__ __forceinline__ void retire_speculation(double* __restrict__ sums, co
 // nblk_spec / nblk_geom: blocks per image of the kernel that wrote them (geometry tail of the speculative
 // forward, or the geometry pass).
 template <typename T>
-__global__ void pairs_pose_reduce_kernel(PairBatch<T> pb, int B, int nblk_spec, int nblk_geom, const T* __restrict__ K,
+__global__ void pairs_pose_reduce_kernel(PairBatch<T> pb, int B, int nblk_geom, const T* __restrict__ K,
                                          const T* __restrict__ g_photo, const T* __restrict__ g_geom) {
   const int pair = blockIdx.x / B, b = blockIdx.x - pair * B;
   const PairArgs<T>& pa = pb.p[pair];
   const bool spec = spec_valid(pa.sums, g_photo, g_geom);
-  pose_reduce_one(b, spec ? nblk_spec : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K, pa.gPp,
+  pose_reduce_one(b, spec ? int(pa.sums[11]) : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K, pa.gPp,
                   pa.sums, g_photo, g_geom, pa.g_pose);
   if (b == 0 && threadIdx.x == 0) retire_speculation(pa.sums, g_photo, g_geom);
 }
@@ -799,7 +800,7 @@ struct alignas(16) Quad { T v[16 / sizeof(T)]; };  // 16-byte vector access
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T> cb, size_t n, PairBatch<T> pb, int npairs,
-                                                                 int B, int nblk_spec, int nblk_geom,
+                                                                 int B, int nblk_geom,
                                                                  const T* __restrict__ K, const T* __restrict__ g_photo,
                                                                  const T* __restrict__ g_geom) {
   // row 0 of the grid is dispatched first: the pose waves (one latency-bound reduction each) start at once and
@@ -811,8 +812,8 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
       const int pair = item / B, b = item - pair * B;
       const PairArgs<T>& pa = pb.p[pair];
       const bool spec = spec_valid(pa.sums, g_photo, g_geom);
-      pose_reduce_one(b, spec ? nblk_spec : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K, pa.gPp,
-                      pa.sums, g_photo, g_geom, pa.g_pose);
+      pose_reduce_one(b, spec ? int(pa.sums[11]) : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K,
+                      pa.gPp, pa.sums, g_photo, g_geom, pa.g_pose);
       if (b == 0 && (threadIdx.x & (kWave - 1)) == 0) retire_speculation(pa.sums, g_photo, g_geom);
     }
     return;
@@ -933,10 +934,16 @@ static bool spec_uses_strips() {
   }();
   return strips;
 }
-// workgroup-level partial records per image the speculative forward leaves (pose partials, sums)
-template <typename T>
-static int spec_nblk(int H, int W) {
-  return spec_uses_strips() ? strip_nbx(W) * strip_nby(H) : ceil_div(W, kTileW - 2) * ceil_div(H, Tile<T>::kH - 2);
+// Waves the device holds of the strip kernel (2 per SIMD): what strip_rows() balances the launch against.
+static int strip_slots() {
+  static const int slots = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0)
+      cus = 256;
+    return cus * 8;
+  }();
+  return slots;
 }
 
 // Forward of up to kMaxPairs pair-directions per launch.  `spec`: every pair has a gbuf and w_photo != 0.
@@ -956,14 +963,15 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
     if (timed) (void)hipEventRecord(g_profile.start[g_profile.used], stream);
     if (spec_uses_strips()) {
       // one wave per (pair, batch element, 32-row segment, 60-column strip); kStripWaves of them per workgroup
-      const int nbx = strip_nbx(W), nby = strip_nby(H), nunits = nbx * nby * n * B;
+      const int nbx = strip_nbx(W), rs = strip_rows(H, nbx * n * B, strip_slots()), nby = ceil_div(H, rs);
+      const int nunits = nbx * nby * n * B;
       grid = dim3(nbx, nby, n * B);  // (what the finalize kernel sizes its reduction by: units per pair = nbx * nby * B)
       const dim3 launch_grid(ceil_div(nunits, kStripWaves));
       if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags)
         hipLaunchKernelGGL((pair_strip_kernel<T, kTrainFlags>), launch_grid, dim3(kThreads), 0, stream, pb, B, H, W, nbx, nby,
-                           nunits, flags, r_hint);
+                           rs, nunits, flags, r_hint);
       else
-        hipLaunchKernelGGL((pair_strip_kernel<T>), launch_grid, dim3(kThreads), 0, stream, pb, B, H, W, nbx, nby, nunits,
+        hipLaunchKernelGGL((pair_strip_kernel<T>), launch_grid, dim3(kThreads), 0, stream, pb, B, H, W, nbx, nby, rs, nunits,
                            flags & ~SCSFM_DEBUG_KERNEL_ONLY, r_hint);
     } else {
       grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
@@ -986,7 +994,7 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
   }
   if (!kernel_only)
     hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(n), dim3(kThreads), 0, stream, pb, (int)(grid.x * grid.y * B),
-                       spec ? 1.0 : 0.0, spec ? w_photo : 0.0, spec ? w_geom : 0.0, total, first ? 1 : 0);
+                       (int)(grid.x * grid.y), spec ? 1.0 : 0.0, spec ? w_photo : 0.0, spec ? w_geom : 0.0, total, first ? 1 : 0);
   return launch_status();
 }
 
@@ -1047,8 +1055,8 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
                          g_photo, g_geom);
     }
     if (flags & SCSFM_DEBUG_SKIP_GEOM) {
-      hipLaunchKernelGGL((pairs_pose_reduce_kernel<T>), dim3(m * B), dim3(kWave), 0, stream, pb, B, spec_nblk<T>(H, W),
-                         nbx * nby, K, g_photo, g_geom);
+      hipLaunchKernelGGL((pairs_pose_reduce_kernel<T>), dim3(m * B), dim3(kWave), 0, stream, pb, B, nbx * nby, K, g_photo,
+                         g_geom);
     } else {
       // group the private planes by the caller's destination buffer: a pair's dense plane belongs to its
       // target depth map, its scatter plane to its reference depth map
@@ -1078,7 +1086,7 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
       gx = gx < gpose ? gpose : gx;
       // (+ 1 row of workgroups: dL/dpose)
       hipLaunchKernelGGL((pairs_combine_kernel<T>), dim3(gx, cb.nd + 1), dim3(kThreads), 0, stream, cb, npx, pb, m, B,
-                         spec_nblk<T>(H, W), nbx * nby, K, g_photo, g_geom);
+                         nbx * nby, K, g_photo, g_geom);
     }
   }
   return launch_status();

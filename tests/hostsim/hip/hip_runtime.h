@@ -256,3 +256,6 @@ static inline float __builtin_amdgcn_fmed3f(float x, float a, float b) {
   return x < lo ? lo : (x > hi ? hi : x);
 }
 static inline void __builtin_amdgcn_wave_barrier() { hostsim::wave_barrier(); }
+enum { hipDeviceAttributeMultiprocessorCount = 1 };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 256; return hipSuccess; }
