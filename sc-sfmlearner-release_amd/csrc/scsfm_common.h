@@ -214,4 +214,29 @@ __device__ __forceinline__ int t_clampi(int x, int lo, int hi) { return x < lo ?
 __device__ __forceinline__ float t_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double t_sqrt(double x) { return sqrt(x); }
 
+// ------------------------------------------------------------------------------------------------------
+// lane <- neighbouring lane (DPP wave shift; lanes without a neighbour read 0).  The compiler folds the shift into
+// the consuming add / fmac (v_add_f32_dpp ... wave_shr:1); half-rate VALU, no LDS traffic.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_left(float v) {   // value of lane - 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_right(float v) {  // value of lane + 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double lane_left(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x138, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x138, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double lane_right(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x130, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x130, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <typename T> __device__ __forceinline__ T box3(T v) { return (v + lane_left(v)) + lane_right(v); }
+
+
 }  // namespace scsfm

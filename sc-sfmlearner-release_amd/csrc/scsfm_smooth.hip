@@ -19,21 +19,26 @@ namespace scsfm {
 #ifndef SCSFM_SMOOTH_ROWS  // tuning knob (tools/build_variants.sh)
 #define SCSFM_SMOOTH_ROWS 4
 #endif
-constexpr int kSmRows = SCSFM_SMOOTH_ROWS;  // rows per thread
+constexpr int kSmRows = SCSFM_SMOOTH_ROWS;  // rows per thread (backward)
+constexpr int kSmFwdRows = 8;                // rows per thread of the forward
+constexpr int kSmFwdCols = kWave - 2;        // owned columns per wave of the forward (lanes 1 .. 62; 0 and 63 are halo)
 constexpr int kMaxFrames = 8;
 
 struct SmoothWs {
   size_t off_img, off_partials, off_counter, total;
-  int nbx, nby;
+  int nbx, nby;    // tiling of the backward (64 x 4 kSmRows pixels per workgroup)
+  int fbx, fby;    // tiling of the forward (62 x 4 kSmFwdRows): the partial sums it leaves
 };
 inline SmoothWs smooth_ws_layout(int B, int H, int W) {
   SmoothWs l;
   l.nbx = ceil_div(W, kWave);
   l.nby = ceil_div(H, kSmRows * (kThreads / kWave));
+  l.fbx = ceil_div(W, kSmFwdCols);
+  l.fby = ceil_div(H, kSmFwdRows * (kThreads / kWave));
   l.off_img = 0;                                   // double[B][2] = {den_b, L_b}
   l.off_partials = (size_t)B * 2 * sizeof(double); // double[B][nby*nbx][3]
   // (+ 256 bytes whose first word is the "finalize blocks done" counter of a multi-frame call)
-  l.off_counter = (l.off_partials + (size_t)B * l.nbx * l.nby * 3 * sizeof(double) + 255) & ~(size_t)255;
+  l.off_counter = (l.off_partials + (size_t)B * l.fbx * l.fby * 3 * sizeof(double) + 255) & ~(size_t)255;
   l.total = l.off_counter + 256;
   return l;
 }
@@ -77,60 +82,55 @@ __device__ __forceinline__ T edge_weight(const Px<T>& a, const Px<T>& b) {
 }
 
 template <typename T>
+__device__ __forceinline__ Px<T> lane_right_px(const Px<T>& v) {
+  Px<T> r;
+  r.d = lane_right(v.d); r.c0 = lane_right(v.c0); r.c1 = lane_right(v.c1); r.c2 = lane_right(v.c2);
+  return r;
+}
+
+// Forward.  A wave covers 64 columns of which it owns 62 (lanes 0 and 63 are halo: they only supply the left / right
+// neighbour) and a thread walks a column strip of kSmFwdRows rows plus the row above and the row below it, so every
+// pixel value is loaded ~1.3 times (round 1: 2.5 times -- the right neighbours were loaded instead of taken from
+// the adjacent lane, strips were 4 rows) and no load sits behind a divergent branch.  Horizontal neighbours come from
+// the adjacent lanes through DPP.
+template <typename T>
 __global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(SmoothBatch<T> sb, int B, int H, int W) {
   __shared__ double red[3 * (kThreads / kWave)];
   const int frame = blockIdx.z / B, b = blockIdx.z - frame * B;
   const SmoothFrame<T>& fr = sb.f[frame];
   const int lane = threadIdx.x & (kWave - 1);
-  const int x = blockIdx.x * kWave + lane;
-  const int y0 = (blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave) * kSmRows;
+  const int x = blockIdx.x * kSmFwdCols - 1 + lane;
+  const int y0 = (blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave) * kSmFwdRows;
   const unsigned plane = unsigned(H) * unsigned(W);
   const T* __restrict__ depth = fr.depth + (size_t)b * plane;
   const T* __restrict__ img = fr.img + (size_t)b * 3 * plane;
   T* __restrict__ edge = fr.edge ? fr.edge + (size_t)b * plane : nullptr;
-  const bool in_x = x < W;
-  const int xc = in_x ? x : W - 1;
+  const bool own_x = lane >= 1 && lane <= kSmFwdCols && x < W;
+  const bool has_right = x >= 0 && x + 1 < W;  // the edge (x, x + 1) exists (also evaluated by the left halo lane)
+  const int xc = x < 0 ? 0 : (x < W ? x : W - 1);
   const T icx = T(1.0 / ((double)B * H * (W - 1))), icy = T(1.0 / ((double)B * (H - 1) * W));
   T sd = T(0), sx = T(0), sy = T(0);
-  // every load of the strip first (the rows, each row's right neighbour, and -- for the stored gradient terms --
-  // the row above and lane 0's left neighbours): one memory round trip, no load behind a divergent branch later
-  Px<T> row[kSmRows + 1], rgt[kSmRows], lft[kSmRows], up = {T(0), T(0), T(0), T(0)};
-  const int xr = x + 1 < W ? x + 1 : W - 1;
+  // every load of the strip first: rows y0 - 1 .. y0 + kSmFwdRows (clamped into the image)
+  Px<T> row[kSmFwdRows + 2];
 #pragma unroll
-  for (int r = 0; r <= kSmRows; ++r)
-    row[r] = load_px(depth, img, plane, unsigned(y0 + r < H ? y0 + r : H - 1) * unsigned(W) + unsigned(xc));
-#pragma unroll
-  for (int r = 0; r < kSmRows; ++r) {
-    rgt[r] = load_px(depth, img, plane, unsigned(y0 + r < H ? y0 + r : H - 1) * unsigned(W) + unsigned(xr));
-    lft[r] = rgt[r];  // (defined for every lane; only lane 0 replaces and uses it)
+  for (int r = 0; r < kSmFwdRows + 2; ++r) {
+    const int y = y0 - 1 + r;
+    row[r] = load_px(depth, img, plane, unsigned(y < 0 ? 0 : (y < H ? y : H - 1)) * unsigned(W) + unsigned(xc));
   }
-  if (edge) {  // workgroup-uniform
-    if (y0 > 0 && y0 < H) up = load_px(depth, img, plane, unsigned(y0 - 1) * unsigned(W) + unsigned(xc));
-    if (lane == 0 && x > 0 && in_x) {
+  // lower edge of the row above the strip (only the stored gradient terms need it)
+  T ty_prev = (y0 > 0 && y0 < H) ? t_sgn(row[0].d - row[1].d) * edge_weight(row[0], row[1]) * icy : T(0);
 #pragma unroll
-      for (int r = 0; r < kSmRows; ++r)
-        lft[r] = load_px(depth, img, plane, unsigned(y0 + r < H ? y0 + r : H - 1) * unsigned(W) + unsigned(x - 1));
-    }
-  }
-  T ty_prev = T(0);  // lower edge of the row above the strip (only needed for the stored gradient terms)
-  if (edge && y0 > 0 && y0 < H) ty_prev = t_sgn(up.d - row[0].d) * edge_weight(up, row[0]) * icy;
-#pragma unroll
-  for (int r = 0; r < kSmRows; ++r) {
+  for (int r = 0; r < kSmFwdRows; ++r) {
     const int y = y0 + r;
-    const unsigned p = unsigned(y < H ? y : H - 1) * unsigned(W) + unsigned(xc);
-    const Px<T> cur = row[r], right = rgt[r], down = row[r + 1];
-    const bool ex = in_x && y < H && x + 1 < W, ey = in_x && y < H && y + 1 < H;
+    const Px<T> cur = row[r + 1], down = row[r + 2], right = lane_right_px(cur);
+    const bool ex = has_right && y < H, ey = y < H && y + 1 < H;
     const T wx = ex ? edge_weight(cur, right) : T(0), wy = ey ? edge_weight(cur, down) : T(0);
     const T dx = cur.d - right.d, dy = cur.d - down.d;
-    if (in_x && y < H) sd += cur.d;
-    sx += t_abs(dx) * wx;
-    sy += t_abs(dy) * wy;
+    if (own_x && y < H) { sd += cur.d; sx += t_abs(dx) * wx; sy += t_abs(dy) * wy; }
     if (edge) {  // workgroup-uniform
       const T tx = t_sgn(dx) * wx * icx, ty = t_sgn(dy) * wy * icy;
-      T tx_left = __shfl_up(tx, 1);
-      if (lane == 0)
-        tx_left = (x > 0 && in_x && y < H) ? t_sgn(lft[r].d - cur.d) * edge_weight(lft[r], cur) * icx : T(0);
-      if (in_x && y < H) st_at(edge, p * unsigned(sizeof(T)), tx - tx_left + ty - ty_prev);
+      const T tx_left = lane_left(tx);  // the pixel's left edge is its left neighbour's right edge
+      if (own_x && y < H) st_at(edge, (unsigned(y) * unsigned(W) + unsigned(x)) * unsigned(sizeof(T)), tx - tx_left + ty - ty_prev);
       ty_prev = ty;
     }
   }
@@ -280,8 +280,8 @@ static int smooth_multi_fwd(int n, const void* const* depths, const void* const*
     sb.counter = reinterpret_cast<unsigned*>((char*)ws + (size_t)i0 * l.total + l.off_counter);
     sb.total = total;
     sb.first = i0 == 0 ? 1 : 0;
-    hipLaunchKernelGGL((smooth_fwd_kernel<T>), dim3(l.nbx, l.nby, m * B), dim3(kThreads), 0, stream, sb, B, H, W);
-    hipLaunchKernelGGL((smooth_finalize_kernel<T>), dim3(m), dim3(kThreads), 0, stream, sb, B, H, W, l.nbx * l.nby);
+    hipLaunchKernelGGL((smooth_fwd_kernel<T>), dim3(l.fbx, l.fby, m * B), dim3(kThreads), 0, stream, sb, B, H, W);
+    hipLaunchKernelGGL((smooth_finalize_kernel<T>), dim3(m), dim3(kThreads), 0, stream, sb, B, H, W, l.fbx * l.fby);
   }
   return launch_status();
 }

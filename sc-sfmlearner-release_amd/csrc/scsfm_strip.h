@@ -60,30 +60,6 @@ inline int strip_rows(int H, int units_per_row_block, int slots) {
 template <typename T> struct StripCell { typedef typename WinCell<T>::type type; };  // fixed point / fp64 (scsfm_geom.h)
 
 // ------------------------------------------------------------------------------------------------------
-// lane <- neighbouring lane (DPP wave shift; lanes without a neighbour read 0).  The compiler folds the shift into
-// the consuming add / fmac (v_add_f32_dpp ... wave_shr:1).
-// ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lane_left(float v) {   // value of lane - 1
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float lane_right(float v) {  // value of lane + 1
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
-}
-__device__ __forceinline__ double lane_left(double v) {
-  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x138, 0xf, 0xf, true);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x138, 0xf, 0xf, true);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ double lane_right(double v) {
-  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x130, 0xf, 0xf, true);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x130, 0xf, 0xf, true);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-template <typename T> __device__ __forceinline__ T box3(T v) { return (v + lane_left(v)) + lane_right(v); }
-
-// ------------------------------------------------------------------------------------------------------
 // What a lane keeps of one row until the row's gradients are finished two steps later: the colours, the mask terms
 // and where the pixel landed.  Everything else the geometry tail needs (tap values, weights, their slopes, X, Y,
 // 1/Z) is re-derived there from `d`, `ix`, `iy` and a second gather that is issued at the top of the step and
