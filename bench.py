@@ -320,7 +320,7 @@ def main():
     lib = _lib.get()
     assert lib.path.endswith(".so") and os.path.exists(lib.path)  # the HIP library, never a fallback
     ident = library_identity(lib)
-    assert ident["abi_version"] == 3, ident
+    assert ident["abi_version"] == _lib.ABI_VERSION, ident
 
     flags = (1, 1, 1, "zeros")  # with_ssim, with_mask, with_auto_mask, padding_mode (scripts/train_resnet18_depth_256.sh)
 

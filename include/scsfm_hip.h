@@ -32,6 +32,9 @@ extern "C" {
 #define SCSFM_WITH_MASK 2u      /* loss_functions.py:111 */
 #define SCSFM_WITH_AUTO_MASK 4u /* loss_functions.py:103 */
 #define SCSFM_PAD_BORDER 8u     /* padding_mode == 'border' (default 'zeros'), inverse_warp.py:219-224,262 */
+#define SCSFM_ROT_QUAT_FLAG 32u /* warp entry points only: the pose's rotation is a quaternion (legacy inverse_warp's
+                                   rotation_mode='quat', inverse_warp.py:139-154,157-191); default euler */
+#define SCSFM_C2P_OVERWRITE 64u /* scsfm_cam2pixel_* only: cam2pixel2's zeros-mode overwrite (inverse_warp.py:219-224) */
 #define SCSFM_LEGACY_GRID 16u   /* warp entry points only: no zeros-mode coordinate overwrite, as the
                                    legacy inverse_warp / cam2pixel (inverse_warp.py:47-74,157-191) */
 
@@ -56,7 +59,8 @@ extern "C" {
 
 /* ABI version of this header; bumped on any change of a signature or of what an entry point does with its
  * buffers (2: the batched backwards store their depth gradients; scratch holds six planes.  3: scsfm_smooth_multi_bwd
- * takes `accumulate`; scsfm_step_total / scsfm_step_weights; scsfm_pair_desc::total). */
+ * takes `accumulate`; scsfm_step_total / scsfm_step_weights; scsfm_pair_desc::total.  4: scsfm_pixel2cam_*, scsfm_cam2pixel_*,
+ * SCSFM_ROT_QUAT_FLAG for the warp entry points). */
 int scsfm_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -168,7 +172,7 @@ int scsfm_pairs_bwd_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, co
  * (0/1), projected_depth [B,1,H,W], computed_depth [B,1,H,W] (all store).  The backward takes the
  * upstream gradients of the three differentiable maps (any may be NULL) and produces g_depth
  * (accumulate), g_ref_depth (accumulate, atomic scatter), g_pose [B,6] (store).  `ws` needs
- * scsfm_warp_ws_bytes(B) bytes.  Only SCSFM_PAD_BORDER and SCSFM_LEGACY_GRID are read from `flags`.
+ * scsfm_warp_ws_bytes(B) bytes.  Only SCSFM_PAD_BORDER, SCSFM_LEGACY_GRID and SCSFM_ROT_QUAT_FLAG are read from `flags`.
  * --------------------------------------------------------------------------------------------- */
 size_t scsfm_warp_ws_bytes(int B);
 
@@ -190,6 +194,32 @@ int scsfm_warp_bwd_f64(int B, int H, int W, const double* img, const double* dep
                        unsigned flags, void* ws, const double* g_projected_img,
                        const double* g_projected_depth, const double* g_computed_depth,
                        double* g_depth, double* g_ref_depth, double* g_pose, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * pixel2cam (inverse_warp.py:29-44): depth [B,H,W], intrinsics_inv [B,3,3] -> cam [B,3,H,W] (store) =
+ * K^-1 (u, v, 1) * depth.  Backward: g_cam [B,3,H,W] -> g_depth [B,H,W] (store).  (No gradient with respect to
+ * intrinsics_inv: intrinsics are data on this path.)
+ * cam2pixel (inverse_warp.py:47-74) and cam2pixel2 (:194-227; flags = SCSFM_C2P_OVERWRITE for padding_mode 'zeros',
+ * z != NULL): cam [B,3,H,W], rot [B,3,3] or NULL, tr [B,3] or NULL -> grid [B,H,W,2] (store) and, optionally, the
+ * clamped depth z [B,1,H,W] (store).  Backward: g_grid [B,H,W,2], g_z [B,1,H,W] or NULL -> g_cam [B,3,H,W] (store)
+ * and g_rot_tr [B][12] fp64 (store: dL/d rot row-major, then dL/d tr).
+ * --------------------------------------------------------------------------------------------- */
+int scsfm_pixel2cam_fwd_f32(int B, int H, int W, const float* depth, const float* intrinsics_inv, float* cam,
+                            void* stream);
+int scsfm_pixel2cam_bwd_f32(int B, int H, int W, const float* intrinsics_inv, const float* g_cam, float* g_depth,
+                            void* stream);
+int scsfm_cam2pixel_fwd_f32(int B, int H, int W, const float* cam, const float* rot, const float* tr, unsigned flags,
+                            float* grid, float* z, void* stream);
+int scsfm_cam2pixel_bwd_f32(int B, int H, int W, const float* cam, const float* rot, const float* tr, unsigned flags,
+                            const float* g_grid, const float* g_z, float* g_cam, double* g_rot_tr, void* stream);
+int scsfm_pixel2cam_fwd_f64(int B, int H, int W, const double* depth, const double* intrinsics_inv, double* cam,
+                            void* stream);
+int scsfm_pixel2cam_bwd_f64(int B, int H, int W, const double* intrinsics_inv, const double* g_cam, double* g_depth,
+                            void* stream);
+int scsfm_cam2pixel_fwd_f64(int B, int H, int W, const double* cam, const double* rot, const double* tr, unsigned flags,
+                            double* grid, double* z, void* stream);
+int scsfm_cam2pixel_bwd_f64(int B, int H, int W, const double* cam, const double* rot, const double* tr, unsigned flags,
+                            const double* g_grid, const double* g_z, double* g_cam, double* g_rot_tr, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * pose_vec2mat (inverse_warp.py:139-154): vec [B,6] = (tx,ty,tz,rx,ry,rz) -> mat [B,3,4] (store);

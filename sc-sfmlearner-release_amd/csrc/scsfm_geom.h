@@ -70,7 +70,7 @@ __device__ __forceinline__ void quat_bwd(T qx, T qy, T qz, const T* g, T* gq3) {
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void prep_one(int b, const T* __restrict__ pose, const T* __restrict__ K,
-                                         BatchConsts<T>* __restrict__ out) {
+                                         BatchConsts<T>* __restrict__ out, bool quat = false) {
   const T* k = K + 9 * b;
   // K^-1 by the adjugate, evaluated in fp64 and rounded once (the reference calls
   // torch.inverse, an LU factorisation; both agree to 1 ulp on camera matrices).
@@ -84,7 +84,8 @@ __device__ __forceinline__ void prep_one(int b, const T* __restrict__ pose, cons
   o.Kinv[6] = T(C02 * inv);  o.Kinv[7] = T(-(a * h - bb * g) * inv);  o.Kinv[8] = T((a * e - bb * d) * inv);
   const T* p = pose + 6 * b;
   T R[9];
-  euler_to_R(p[3], p[4], p[5], R);  // inverse_warp2 always uses euler angles (inverse_warp.py:255)
+  // inverse_warp2 always uses euler angles (inverse_warp.py:255); the legacy inverse_warp takes a rotation_mode
+  if (quat) quat_to_R(p[3], p[4], p[5], R); else euler_to_R(p[3], p[4], p[5], R);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
 #pragma unroll
@@ -97,15 +98,15 @@ __device__ __forceinline__ void prep_one(int b, const T* __restrict__ pose, cons
 
 template <typename T>
 __global__ void prep_kernel(int B, const T* __restrict__ pose, const T* __restrict__ K,
-                            BatchConsts<T>* __restrict__ out) {
+                            BatchConsts<T>* __restrict__ out, int quat) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) prep_one(b, pose, K, out);
+  if (b < B) prep_one(b, pose, K, out, quat != 0);
 }
 
 // dL/d(A|c) (12 numbers, fp64) of one batch element -> dL/dpose: gT = K^T gP, then the euler chain.
 template <typename T>
 __device__ __forceinline__ void pose_from_gP(const T* __restrict__ k, const T* __restrict__ p, const double* g,
-                                             T* __restrict__ o) {
+                                             T* __restrict__ o, bool quat = false) {
   T gR[9], gt[3];
 #pragma unroll
   for (int kk = 0; kk < 3; ++kk) {
@@ -115,7 +116,7 @@ __device__ __forceinline__ void pose_from_gP(const T* __restrict__ k, const T* _
     gt[kk] = T(double(k[kk]) * g[9] + double(k[3 + kk]) * g[10] + double(k[6 + kk]) * g[11]);
   }
   T ga[3];
-  euler_bwd(p[3], p[4], p[5], gR, ga);
+  if (quat) quat_bwd(p[3], p[4], p[5], gR, ga); else euler_bwd(p[3], p[4], p[5], gR, ga);
   o[0] = gt[0]; o[1] = gt[1]; o[2] = gt[2];
   o[3] = ga[0]; o[4] = ga[1]; o[5] = ga[2];
 }
@@ -123,13 +124,13 @@ __device__ __forceinline__ void pose_from_gP(const T* __restrict__ k, const T* _
 // gP [B][12] accumulated with atomics (warp_bwd path); re-zeroed after use.
 template <typename T>
 __global__ void pose_bwd_kernel(int B, const T* __restrict__ pose, const T* __restrict__ K,
-                                double* __restrict__ gP, T* __restrict__ gpose) {
+                                double* __restrict__ gP, T* __restrict__ gpose, int quat) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   double g[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) { g[i] = gP[12 * b + i]; gP[12 * b + i] = 0.0; }  // consumed: ready for the next backward
-  pose_from_gP(K + 9 * b, pose + 6 * b, g, gpose + 6 * b);
+  pose_from_gP(K + 9 * b, pose + 6 * b, g, gpose + 6 * b, quat != 0);
 }
 
 // One wave per batch element: ordered fp64 reduction of the per-block partials gPp[b][nblk][12]
@@ -244,7 +245,10 @@ __device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int
     if (!(ix > T(0))) { ix = T(0); s.gmx = T(0); } else if (!(ix < T(W - 1))) { ix = T(W - 1); s.gmx = T(0); }
     if (!(iy > T(0))) { iy = T(0); s.gmy = T(0); } else if (!(iy < T(H - 1))) { iy = T(H - 1); s.gmy = T(0); }
   } else {
-    // legacy grid, zeros padding, any coordinate: positions beyond [-1, W] sample nothing, exactly like -1 and W
+    // legacy grid, zeros padding, any coordinate: positions beyond [-1, W] sample nothing, exactly like -1 and W --
+    // and, none of their taps lying inside the image, they have no gradient (grid_sampler_2d_backward)
+    if (!(ix >= T(-1) && ix < T(W))) s.gmx = T(0);
+    if (!(iy >= T(-1) && iy < T(H))) s.gmy = T(0);
     ix = t_med3(ix, T(-1), T(W));
     iy = t_med3(iy, T(-1), T(H));
   }

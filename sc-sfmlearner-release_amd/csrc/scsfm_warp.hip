@@ -116,7 +116,8 @@ static int warp_fwd(int B, int H, int W, const T* img, const T* depth, const T* 
     return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   auto* consts = reinterpret_cast<BatchConsts<T>*>(ws);
-  hipLaunchKernelGGL((prep_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, consts);
+  hipLaunchKernelGGL((prep_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, consts,
+                     (flags & SCSFM_ROT_QUAT_FLAG) ? 1 : 0);
   dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
   hipLaunchKernelGGL((warp_fwd_kernel<T>), grid, dim3(kThreads), 0, stream, H, W, flags,
                      img, depth, ref_depth, (const BatchConsts<T>*)consts, o_img, o_valid, o_pd, o_cd);
@@ -136,13 +137,177 @@ static int warp_bwd(int B, int H, int W, const T* img, const T* depth, const T* 
   double* gP = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + warp_ws_gP_offset(B));
   hipError_t e = hipMemsetAsync(gP, 0, (size_t)B * 12 * sizeof(double), stream);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((prep_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, consts);
+  hipLaunchKernelGGL((prep_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, consts,
+                     (flags & SCSFM_ROT_QUAT_FLAG) ? 1 : 0);
   dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
   hipLaunchKernelGGL((warp_bwd_kernel<T>), grid, dim3(kThreads), 0, stream, H, W, flags,
                      img, depth, ref_depth, (const BatchConsts<T>*)consts, g_img, g_pd, g_cd, g_depth, g_ref_depth,
                      gP);
   hipLaunchKernelGGL((pose_bwd_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K,
-                     gP, g_pose);
+                     gP, g_pose, (flags & SCSFM_ROT_QUAT_FLAG) ? 1 : 0);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// pixel2cam (inverse_warp.py:29-44): cam[b, :, v, u] = K^-1_b (u, v, 1) * depth[b, v, u]
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pixel2cam_fwd_kernel(int H, int W, const T* __restrict__ depth,
+                                                                 const T* __restrict__ Kinv, T* __restrict__ cam) {
+  const int b = blockIdx.z;
+  const int u = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const int v = blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave;
+  if (u >= W || v >= H) return;
+  const T* k = Kinv + 9 * b;
+  const long plane = (long)H * W, p = (long)v * W + u;
+  const T d = depth[b * plane + p], uf = T(u), vf = T(v);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) cam[(b * 3 + i) * plane + p] = (k[3 * i] * uf + k[3 * i + 1] * vf + k[3 * i + 2]) * d;
+}
+// dL/d depth = <ray, dL/d cam>  (store)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pixel2cam_bwd_kernel(int H, int W, const T* __restrict__ Kinv,
+                                                                 const T* __restrict__ g_cam, T* __restrict__ g_depth) {
+  const int b = blockIdx.z;
+  const int u = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const int v = blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave;
+  if (u >= W || v >= H) return;
+  const T* k = Kinv + 9 * b;
+  const long plane = (long)H * W, p = (long)v * W + u;
+  const T uf = T(u), vf = T(v);
+  T g = T(0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) g += (k[3 * i] * uf + k[3 * i + 1] * vf + k[3 * i + 2]) * g_cam[(b * 3 + i) * plane + p];
+  g_depth[b * plane + p] = g;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// cam2pixel (inverse_warp.py:47-74) / cam2pixel2 (:194-227): p = rot cam + tr (either may be absent); Z = max(p_z, 1e-3);
+// grid[b, v, u] = (2 (X/Z)/(W-1) - 1, 2 (Y/Z)/(H-1) - 1); cam2pixel2 (SCSFM_C2P_OVERWRITE) replaces out-of-range
+// coordinates by 2 under zeros padding (no gradient there) and also returns Z.
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void cam2pixel_fwd_kernel(int H, int W, unsigned flags, const T* __restrict__ cam,
+                                                                 const T* __restrict__ rot, const T* __restrict__ tr,
+                                                                 T* __restrict__ grid_out, T* __restrict__ z_out) {
+  const int b = blockIdx.z;
+  const int u = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const int v = blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave;
+  if (u >= W || v >= H) return;
+  const long plane = (long)H * W, p = (long)v * W + u;
+  const T c0 = cam[(b * 3) * plane + p], c1 = cam[(b * 3 + 1) * plane + p], c2 = cam[(b * 3 + 2) * plane + p];
+  T q[3] = {c0, c1, c2};
+  if (rot) {
+    const T* r = rot + 9 * b;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) q[i] = r[3 * i] * c0 + r[3 * i + 1] * c1 + r[3 * i + 2] * c2;
+  }
+  if (tr) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) q[i] += tr[3 * b + i];
+  }
+  const T Z = t_max(q[2], T(kZMin));
+  T xn = T(2) * (q[0] / Z) / T(W - 1) - T(1), yn = T(2) * (q[1] / Z) / T(H - 1) - T(1);
+  if (flags & SCSFM_C2P_OVERWRITE) {
+    if (xn > T(1) || xn < T(-1)) xn = T(2);
+    if (yn > T(1) || yn < T(-1)) yn = T(2);
+  }
+  grid_out[(b * plane + p) * 2] = xn;
+  grid_out[(b * plane + p) * 2 + 1] = yn;
+  if (z_out) z_out[b * plane + p] = Z;
+}
+
+// g_grid [B,H,W,2], g_z [B,1,H,W] (may be NULL) -> g_cam [B,3,H,W] (store), gP [B][12] += (dL/d rot, dL/d tr) in fp64
+template <typename T>
+__global__ __launch_bounds__(kThreads) void cam2pixel_bwd_kernel(int H, int W, unsigned flags, const T* __restrict__ cam,
+                                                                 const T* __restrict__ rot, const T* __restrict__ tr,
+                                                                 const T* __restrict__ g_grid, const T* __restrict__ g_z,
+                                                                 T* __restrict__ g_cam, double* __restrict__ gP) {
+  __shared__ double red[12 * (kThreads / kWave)];
+  const int b = blockIdx.z;
+  const int u = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const int v = blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave;
+  const long plane = (long)H * W, p = (long)v * W + u;
+  T acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = T(0);
+  if (u < W && v < H) {
+    const T c0 = cam[(b * 3) * plane + p], c1 = cam[(b * 3 + 1) * plane + p], c2 = cam[(b * 3 + 2) * plane + p];
+    T q[3] = {c0, c1, c2};
+    const T* r = rot ? rot + 9 * b : nullptr;
+    if (r) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) q[i] = r[3 * i] * c0 + r[3 * i + 1] * c1 + r[3 * i + 2] * c2;
+    }
+    if (tr) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) q[i] += tr[3 * b + i];
+    }
+    const T Z = t_max(q[2], T(kZMin));
+    const T xn = T(2) * (q[0] / Z) / T(W - 1) - T(1), yn = T(2) * (q[1] / Z) / T(H - 1) - T(1);
+    T gx = g_grid[(b * plane + p) * 2] * (T(2) / T(W - 1)), gy = g_grid[(b * plane + p) * 2 + 1] * (T(2) / T(H - 1));
+    if (flags & SCSFM_C2P_OVERWRITE) {  // overwritten coordinates are constants
+      if (xn > T(1) || xn < T(-1)) gx = T(0);
+      if (yn > T(1) || yn < T(-1)) gy = T(0);
+    }
+    const T dq0 = gx / Z, dq1 = gy / Z;
+    const T dq2 = q[2] >= T(kZMin) ? (g_z ? g_z[b * plane + p] : T(0)) - (gx * q[0] + gy * q[1]) / (Z * Z) : T(0);
+    acc[0] = dq0 * c0; acc[1] = dq0 * c1; acc[2] = dq0 * c2;
+    acc[3] = dq1 * c0; acc[4] = dq1 * c1; acc[5] = dq1 * c2;
+    acc[6] = dq2 * c0; acc[7] = dq2 * c1; acc[8] = dq2 * c2;
+    acc[9] = dq0; acc[10] = dq1; acc[11] = dq2;
+    T gc[3] = {dq0, dq1, dq2};
+    if (r) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) gc[j] = r[j] * dq0 + r[3 + j] * dq1 + r[6 + j] * dq2;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g_cam[(b * 3 + j) * plane + p] = gc[j];
+  }
+  block_sum<12>(acc, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) atomicAdd(gP + 12 * b + i, double(acc[i]));
+  }
+}
+
+template <typename T>
+static int pixel2cam_fwd(int B, int H, int W, const T* depth, const T* Kinv, T* cam, void* stream) {
+  clear_status();
+  if (B <= 0 || H < 1 || W < 1 || !depth || !Kinv || !cam) return SCSFM_ERR_ARG;
+  dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
+  hipLaunchKernelGGL((pixel2cam_fwd_kernel<T>), grid, dim3(kThreads), 0, (hipStream_t)stream, H, W, depth, Kinv, cam);
+  return launch_status();
+}
+template <typename T>
+static int pixel2cam_bwd(int B, int H, int W, const T* Kinv, const T* g_cam, T* g_depth, void* stream) {
+  clear_status();
+  if (B <= 0 || H < 1 || W < 1 || !Kinv || !g_cam || !g_depth) return SCSFM_ERR_ARG;
+  dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
+  hipLaunchKernelGGL((pixel2cam_bwd_kernel<T>), grid, dim3(kThreads), 0, (hipStream_t)stream, H, W, Kinv, g_cam, g_depth);
+  return launch_status();
+}
+template <typename T>
+static int cam2pixel_fwd(int B, int H, int W, const T* cam, const T* rot, const T* tr, unsigned flags, T* grid_out, T* z_out,
+                         void* stream) {
+  clear_status();
+  if (B <= 0 || H < 2 || W < 2 || !cam || !grid_out) return SCSFM_ERR_ARG;
+  dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
+  hipLaunchKernelGGL((cam2pixel_fwd_kernel<T>), grid, dim3(kThreads), 0, (hipStream_t)stream, H, W, flags, cam, rot, tr,
+                     grid_out, z_out);
+  return launch_status();
+}
+template <typename T>
+static int cam2pixel_bwd(int B, int H, int W, const T* cam, const T* rot, const T* tr, unsigned flags, const T* g_grid,
+                         const T* g_z, T* g_cam, double* gP, void* stream_) {
+  clear_status();
+  if (B <= 0 || H < 2 || W < 2 || !cam || !g_grid || !g_cam || !gP) return SCSFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipError_t e = hipMemsetAsync(gP, 0, (size_t)B * 12 * sizeof(double), stream);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
+  hipLaunchKernelGGL((cam2pixel_bwd_kernel<T>), grid, dim3(kThreads), 0, stream, H, W, flags, cam, rot, tr, g_grid, g_z, g_cam,
+                     gP);
   return launch_status();
 }
 
@@ -167,7 +332,7 @@ static int pose_bwd(int B, const T* vec, int mode, const T* g_mat, T* g_vec, voi
 
 extern "C" {
 
-int scsfm_abi_version(void) { return 3; }
+int scsfm_abi_version(void) { return 4; }
 
 size_t scsfm_warp_ws_bytes(int B) {
   if (B <= 0) return 0;
@@ -186,6 +351,20 @@ size_t scsfm_warp_ws_bytes(int B) {
                            T* g_depth, T* g_ref_depth, T* g_pose, void* stream) {                                     \
     return scsfm::warp_bwd<T>(B, H, W, img, depth, ref_depth, pose, K, flags, ws, g_img, g_pd, g_cd, g_depth,         \
                               g_ref_depth, g_pose, stream);                                                           \
+  }                                                                                                                   \
+  int scsfm_pixel2cam_fwd_##SUF(int B, int H, int W, const T* depth, const T* Kinv, T* cam, void* stream) {           \
+    return scsfm::pixel2cam_fwd<T>(B, H, W, depth, Kinv, cam, stream);                                               \
+  }                                                                                                                   \
+  int scsfm_pixel2cam_bwd_##SUF(int B, int H, int W, const T* Kinv, const T* g_cam, T* g_depth, void* stream) {       \
+    return scsfm::pixel2cam_bwd<T>(B, H, W, Kinv, g_cam, g_depth, stream);                                           \
+  }                                                                                                                   \
+  int scsfm_cam2pixel_fwd_##SUF(int B, int H, int W, const T* cam, const T* rot, const T* tr, unsigned flags,         \
+                                T* grid, T* z, void* stream) {                                                        \
+    return scsfm::cam2pixel_fwd<T>(B, H, W, cam, rot, tr, flags, grid, z, stream);                                   \
+  }                                                                                                                   \
+  int scsfm_cam2pixel_bwd_##SUF(int B, int H, int W, const T* cam, const T* rot, const T* tr, unsigned flags,         \
+                                const T* g_grid, const T* g_z, T* g_cam, double* g_rot_tr, void* stream) {            \
+    return scsfm::cam2pixel_bwd<T>(B, H, W, cam, rot, tr, flags, g_grid, g_z, g_cam, g_rot_tr, stream);              \
   }                                                                                                                   \
   int scsfm_pose_vec2mat_fwd_##SUF(int B, const T* vec, int mode, T* mat, void* stream) {                             \
     return scsfm::pose_fwd<T>(B, vec, mode, mat, stream);                                                             \

@@ -1,5 +1,10 @@
-"""PairFolder (datasets/pair_folders.py): scenes hold image pairs NNNN_0.jpg / NNNN_1.jpg; a sample is
-(tgt, [ref], K, K^-1) with the two frames in random order."""
+"""PairFolder (datasets/pair_folders.py): the behaviour of the reference's loader for pair data sets.
+
+On-disk contract (datasets/pair_folders.py:14-21,33-45 of the reference): a scene folder holds the frames as
+``*.jpg`` and ONE intrinsics file ``*.txt`` PER PAIR; both lists are taken in sorted order, frames 2k and 2k+1 form
+pair k (target = the first, reference = the second, never swapped) and pair k uses the k-th text file.  A trailing
+unpaired frame is ignored.  The pairs of all scenes are shuffled once with the seeded generator.
+"""
 import os
 import random
 
@@ -9,36 +14,38 @@ import torch.utils.data as data
 from .sequence_folders import load_as_float
 
 
+def _sorted_with_suffix(folder, suffix):
+    return sorted(os.path.join(folder, f) for f in os.listdir(folder) if f.endswith(suffix))
+
+
 class PairFolder(data.Dataset):
     def __init__(self, root, seed=None, train=True, transform=None):
         np.random.seed(seed)
         random.seed(seed)
         self.root = str(root)
-        scene_list = os.path.join(self.root, 'train.txt' if train else 'val.txt')
-        self.scenes = [os.path.join(self.root, line.strip()) for line in open(scene_list) if line.strip()]
+        listing = os.path.join(self.root, 'train.txt' if train else 'val.txt')
+        self.scenes = [os.path.join(self.root, line[:-1] if line.endswith('\n') else line) for line in open(listing)]
         self.transform = transform
-        pairs = []
+        self.samples = self._collect()
+
+    def _collect(self):
+        found = []
         for scene in self.scenes:
-            intrinsics = np.genfromtxt(os.path.join(scene, 'cam.txt')).astype(np.float32).reshape((3, 3))
-            firsts = sorted(f for f in os.listdir(scene) if f.endswith('_0.jpg'))
-            for f in firsts:
-                second = os.path.join(scene, f[:-6] + '_1.jpg')
-                if os.path.exists(second):
-                    pairs.append({'intrinsics': intrinsics, 'a': os.path.join(scene, f), 'b': second})
-        random.shuffle(pairs)
-        self.samples = pairs
+            frames = _sorted_with_suffix(scene, '.jpg')
+            cams = _sorted_with_suffix(scene, '.txt')
+            for k in range(len(frames) // 2):
+                K = np.genfromtxt(cams[k]).astype(np.float32).reshape((3, 3))
+                found.append({'intrinsics': K, 'tgt': frames[2 * k], 'ref_imgs': [frames[2 * k + 1]]})
+        random.shuffle(found)
+        return found
 
     def __getitem__(self, index):
-        s = self.samples[index]
-        a, b = load_as_float(s['a']), load_as_float(s['b'])
-        if random.random() < 0.5:
-            a, b = b, a
+        entry = self.samples[index]
+        frames = [load_as_float(entry['tgt'])] + [load_as_float(p) for p in entry['ref_imgs']]
+        K = np.copy(entry['intrinsics'])
         if self.transform is not None:
-            imgs, intrinsics = self.transform([a, b], np.copy(s['intrinsics']))
-            a, b = imgs
-        else:
-            intrinsics = np.copy(s['intrinsics'])
-        return a, [b], intrinsics, np.linalg.inv(intrinsics)
+            frames, K = self.transform(frames, K)
+        return frames[0], frames[1:], K, np.linalg.inv(K)
 
     def __len__(self):
         return len(self.samples)

@@ -8,8 +8,9 @@ tensors -- there is no CPU path in this package.
 from __future__ import division
 
 import torch
+import torch.nn.functional as F  # noqa: F401  (part of the reference module's namespace: `from inverse_warp import *`)
 
-from scsfm_hip import capi, ops
+from scsfm_hip import capi as _capi, ops as _ops  # (underscored: a star import must bring the reference's names only)
 
 pixel_coords = None  # kept for API compatibility (inverse_warp.py:5); the kernels need no cached grid
 
@@ -41,19 +42,19 @@ def pose_vec2mat(vec, rotation_mode='euler'):
         # the reference falls through to an UnboundLocalError here (inverse_warp.py:149-153)
         raise UnboundLocalError("rotation_mode must be 'euler' or 'quat', got {!r}".format(rotation_mode))
     check_sizes(vec, 'pose', 'B6')
-    return ops.PoseVec2Mat.apply(vec, rotation_mode)
+    return _ops.PoseVec2Mat.apply(vec, rotation_mode)
 
 
 def euler2mat(angle):
     """[B,3] -> [B,3,3], R = Rx Ry Rz (inverse_warp.py:77-112)."""
     vec = torch.cat([torch.zeros_like(angle), angle], dim=1)
-    return ops.PoseVec2Mat.apply(vec, 'euler')[:, :, :3]
+    return _ops.PoseVec2Mat.apply(vec, 'euler')[:, :, :3]
 
 
 def quat2mat(quat):
     """[B,3] -> [B,3,3] (inverse_warp.py:115-136)."""
     vec = torch.cat([torch.zeros_like(quat), quat], dim=1)
-    return ops.PoseVec2Mat.apply(vec, 'quat')[:, :, :3]
+    return _ops.PoseVec2Mat.apply(vec, 'quat')[:, :, :3]
 
 
 def inverse_warp2(img, depth, ref_depth, pose, intrinsics, padding_mode='zeros'):
@@ -68,37 +69,47 @@ def inverse_warp2(img, depth, ref_depth, pose, intrinsics, padding_mode='zeros')
     check_sizes(ref_depth, 'ref_depth', 'B1HW')
     check_sizes(pose, 'pose', 'B6')
     check_sizes(intrinsics, 'intrinsics', 'B33')
-    flags = capi.make_flags(padding_mode=padding_mode)
-    return ops.InverseWarp2.apply(flags, img, depth, ref_depth, pose, intrinsics)
+    flags = _capi.make_flags(padding_mode=padding_mode)
+    return _ops.InverseWarp2.apply(flags, img, depth, ref_depth, pose, intrinsics)
 
 
 def inverse_warp(img, depth, pose, intrinsics, rotation_mode='euler', padding_mode='zeros'):
     """Legacy single-view warp (inverse_warp.py:157-191): depth is [B,H,W]; returns
     (projected_img, valid_points[bool]).  Imported but never called by the reference's loss
-    (loss_functions.py:5).  Served by the same HIP kernel as inverse_warp2; 'euler' only."""
+    (loss_functions.py:5).  Served by the same HIP kernel as inverse_warp2 (euler or quaternion rotation)."""
     check_sizes(img, 'img', 'B3HW')
     check_sizes(depth, 'depth', 'BHW')
     check_sizes(pose, 'pose', 'B6')
     check_sizes(intrinsics, 'intrinsics', 'B33')
-    if rotation_mode != 'euler':
-        raise NotImplementedError("inverse_warp: only rotation_mode='euler' is wired to the HIP kernels")
+    if rotation_mode not in ('euler', 'quat'):
+        raise UnboundLocalError("rotation_mode must be 'euler' or 'quat', got {!r}".format(rotation_mode))
     d = depth.unsqueeze(1)
     # the legacy path has no zeros-mode coordinate overwrite (cam2pixel, inverse_warp.py:47-74)
-    flags = capi.make_flags(padding_mode=padding_mode) | capi.LEGACY_GRID
-    projected_img, valid, _, _ = ops.InverseWarp2.apply(flags, img, d, d.detach(), pose, intrinsics)
+    flags = _capi.make_flags(padding_mode=padding_mode) | _capi.LEGACY_GRID
+    if rotation_mode == 'quat':
+        flags |= _capi.ROT_QUAT_FLAG
+    projected_img, valid, _, _ = _ops.InverseWarp2.apply(flags, img, d, d.detach(), pose, intrinsics)
     return projected_img, valid.squeeze(1) > 0.5
 
 
 def pixel2cam(depth, intrinsics_inv):
-    raise NotImplementedError("pixel2cam is fused into the HIP warp kernels (csrc/scsfm_geom.h: project_pixel); "
-                              "use inverse_warp2")
+    """inverse_warp.py:29-44: depth [B,H,W], intrinsics_inv [B,3,3] -> camera coordinates [B,3,H,W] =
+    K^-1 (u, v, 1) * depth.  One HIP kernel each way (gradient to the depth map)."""
+    check_sizes(depth, 'depth', 'BHW')
+    check_sizes(intrinsics_inv, 'intrinsics_inv', 'B33')
+    return _ops.Pixel2Cam.apply(depth, intrinsics_inv)
 
 
 def cam2pixel(cam_coords, proj_c2p_rot, proj_c2p_tr, padding_mode):
-    raise NotImplementedError("cam2pixel is fused into the HIP warp kernels (csrc/scsfm_geom.h: project_pixel); "
-                              "use inverse_warp2")
+    """inverse_warp.py:47-74: camera coordinates [B,3,H,W], rotation [B,3,3] | None, translation [B,3,1] | None ->
+    normalised sampling grid [B,H,W,2].  (``padding_mode`` is unused by the reference too.)"""
+    check_sizes(cam_coords, 'cam_coords', 'B3HW')
+    return _ops.Cam2Pixel.apply(0, False, cam_coords, proj_c2p_rot, proj_c2p_tr)
 
 
 def cam2pixel2(cam_coords, proj_c2p_rot, proj_c2p_tr, padding_mode):
-    raise NotImplementedError("cam2pixel2 is fused into the HIP warp kernels (csrc/scsfm_geom.h: project_pixel); "
-                              "use inverse_warp2")
+    """inverse_warp.py:194-227 -> (grid [B,H,W,2], computed depth [B,1,H,W]); under 'zeros' padding out-of-range
+    coordinates are overwritten with 2 (and carry no gradient)."""
+    check_sizes(cam_coords, 'cam_coords', 'B3HW')
+    flags = _capi.C2P_OVERWRITE if padding_mode == 'zeros' else 0
+    return _ops.Cam2Pixel.apply(flags, True, cam_coords, proj_c2p_rot, proj_c2p_tr)

@@ -23,6 +23,8 @@ HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "scsfm_
 # SCSFM_HIP_LIB points at a library built elsewhere (tuning variants, a system-wide install)
 LIB_PATH = os.environ.get("SCSFM_HIP_LIB") or os.path.join(HERE, "libscsfm_hip.so")
 
+ABI_VERSION = 4  # include/scsfm_hip.h
+
 _CTYPES = {"int": ctypes.c_int, "unsigned": ctypes.c_uint, "size_t": ctypes.c_size_t, "double": ctypes.c_double}
 _DECL = re.compile(r"^(int|size_t)\s+(scsfm_\w+)\s*\(([^)]*)\)\s*;", re.M | re.S)
 
@@ -66,7 +68,7 @@ class CLib:
             fn.restype = ret
             fn.argtypes = argtypes
             self._fn[name] = fn
-        if self._dll.scsfm_abi_version() != 3:
+        if self._dll.scsfm_abi_version() != ABI_VERSION:
             raise ScsfmError(f"{path}: ABI version mismatch")
 
     def call(self, name, *args):

@@ -11,6 +11,7 @@ import torch
 from . import _lib
 
 WITH_SSIM, WITH_MASK, WITH_AUTO_MASK, PAD_BORDER, LEGACY_GRID = 1, 2, 4, 8, 16
+ROT_QUAT_FLAG, C2P_OVERWRITE = 32, 64
 ROT = {"euler": 0, "quat": 1}
 
 
@@ -93,6 +94,46 @@ def warp_bwd(lib, img, depth, ref_depth, pose, K, flags, g_img, g_pd, g_cd):
     lib.call(f"scsfm_warp_bwd_{_suffix(img)}", B, H, W, _p(img), _p(depth), _p(ref_depth), _p(pose), _p(K), flags,
              _p(ws), _p(g_img), _p(g_pd), _p(g_cd), _p(g_depth), _p(g_ref), _p(g_pose), _stream(img))
     return g_depth, g_ref, g_pose
+
+
+# -- pixel2cam / cam2pixel / cam2pixel2 ----------------------------------------------------------
+def pixel2cam_fwd(lib, depth, Kinv):
+    """depth [B,H,W], intrinsics_inv [B,3,3] -> cam [B,3,H,W] (inverse_warp.py:29-44)."""
+    _chk(depth, Kinv)
+    B, H, W = depth.shape
+    cam = torch.empty((B, 3, H, W), dtype=depth.dtype, device=depth.device)
+    lib.call(f"scsfm_pixel2cam_fwd_{_suffix(depth)}", B, H, W, _p(depth), _p(Kinv), _p(cam), _stream(depth))
+    return cam
+
+
+def pixel2cam_bwd(lib, Kinv, g_cam):
+    _chk(Kinv, g_cam)
+    B, _, H, W = g_cam.shape
+    g_depth = torch.empty((B, H, W), dtype=g_cam.dtype, device=g_cam.device)
+    lib.call(f"scsfm_pixel2cam_bwd_{_suffix(g_cam)}", B, H, W, _p(Kinv), _p(g_cam), _p(g_depth), _stream(g_cam))
+    return g_depth
+
+
+def cam2pixel_fwd(lib, cam, rot, tr, flags, want_z):
+    """cam [B,3,H,W], rot [B,3,3] | None, tr [B,3,1] | None -> grid [B,H,W,2] (+ z [B,1,H,W])
+    (inverse_warp.py:47-74, 194-227)."""
+    _chk(cam, rot, tr)
+    B, _, H, W = cam.shape
+    grid = torch.empty((B, H, W, 2), dtype=cam.dtype, device=cam.device)
+    z = torch.empty((B, 1, H, W), dtype=cam.dtype, device=cam.device) if want_z else None
+    lib.call(f"scsfm_cam2pixel_fwd_{_suffix(cam)}", B, H, W, _p(cam), _p(rot), _p(tr), flags, _p(grid), _p(z), _stream(cam))
+    return grid, z
+
+
+def cam2pixel_bwd(lib, cam, rot, tr, flags, g_grid, g_z):
+    """-> g_cam [B,3,H,W], g_rot [B,3,3], g_tr [B,3,1] (the latter two reduced in fp64 on the device)."""
+    _chk(cam, rot, tr, g_grid, g_z)
+    B, _, H, W = cam.shape
+    g_cam = torch.empty_like(cam)
+    acc = torch.empty((B, 12), dtype=torch.float64, device=cam.device)
+    lib.call(f"scsfm_cam2pixel_bwd_{_suffix(cam)}", B, H, W, _p(cam), _p(rot), _p(tr), flags, _p(g_grid), _p(g_z), _p(g_cam),
+             _p(acc), _stream(cam))
+    return g_cam, acc[:, :9].reshape(B, 3, 3).to(cam.dtype), acc[:, 9:].reshape(B, 3, 1).to(cam.dtype)
 
 
 # -- pose_vec2mat ------------------------------------------------------------------------------

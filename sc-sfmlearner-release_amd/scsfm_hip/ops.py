@@ -70,6 +70,7 @@ class PhotoGeometryLoss(torch.autograd.Function):
         photo, geom, _, ws = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
                                                      poses_inv, group=_dist.exact_group(), hint=hint)
         ctx.flags, ctx.n_ref, ctx.n_scales = flags, n_ref, n_scales
+        ctx.spec_hint = hint
         ctx.save_for_backward(tgt_img, K, *rest, ws)
         return photo, geom
 
@@ -82,11 +83,36 @@ class PhotoGeometryLoss(torch.autograd.Function):
         _no_grad_inputs(ctx, 3, ["tgt_img", "intrinsics"] + [f"ref_imgs[{i}]" for i in range(n_ref)])
         ref_imgs, tgt_depths, ref_depths, poses, poses_inv, n_in = PhotoGeometryLoss._split(saved[2:], n_ref, n_scales)
         ws = saved[2 + n_in]
+        _check_hint_once(ctx, g_photo, g_geom)
         g_td, g_rd, g_poses, g_poses_inv = capi.photo_geometry_bwd(
             lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws,
             _scalar(g_photo, tgt_img), _scalar(g_geom, tgt_img))
         return (None, None, None, None, None, *([None] * n_ref), *g_td, *[g for r in g_rd for g in r], *g_poses,
                 *g_poses_inv)
+
+
+_hint_checked = False
+
+
+def _check_hint_once(ctx, g_photo, g_geom):
+    """The first backward of a process compares the upstream gradients with the weight hint the forward speculated
+    on (one host read-back, once): a mismatch is never wrong -- the device falls back to its two backward passes --
+    but it costs ~0.5 ms per step at KITTI size, and a drop-in user with other loss weights should hear about it."""
+    global _hint_checked
+    if _hint_checked or not getattr(ctx, "spec_hint", None) or g_photo is None or g_geom is None:
+        return
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return  # (no host read-back inside a graph capture; checked on the next eager backward)
+    _hint_checked = True
+    wp, wg = ctx.spec_hint
+    gp, gg = float(g_photo), float(g_geom)
+    if abs(gp * wg - gg * wp) > 1e-6 * max(abs(gp * wg), abs(gg * wp), 1e-30):
+        import warnings
+        warnings.warn(f"scsfm_hip: the loss weights arriving in backward (photo {gp:g}, geometry {gg:g}) do not stand in "
+                      f"the ratio the forward speculated on ({wp:g} : {wg:g}); results are unaffected, but every step "
+                      "now runs the two-pass backward.  Call scsfm_hip.config.set_weight_hint(w_photo, w_geom) with the "
+                      "weights of `w1*loss_1 + w3*loss_3` (train.py:268), or set_weight_hint(None, None) to disable "
+                      "speculation.", RuntimeWarning, stacklevel=3)
 
 
 class PairwiseLoss(torch.autograd.Function):
@@ -225,6 +251,53 @@ class InverseWarp2(torch.autograd.Function):
         g_depth, g_ref, g_pose = capi.warp_bwd(lib, img, depth, ref_depth, pose, K, ctx.flags, cc(g_img), cc(g_pd),
                                                cc(g_cd))
         return None, None, g_depth, g_ref, g_pose, None
+
+
+class Pixel2Cam(torch.autograd.Function):
+    """pixel2cam (inverse_warp.py:29-44): depth [B,H,W], intrinsics_inv [B,3,3] -> [B,3,H,W]."""
+
+    @staticmethod
+    def forward(ctx, depth, Kinv):
+        depth, Kinv = _c(depth), _c(Kinv)
+        _need_cuda(depth, Kinv)
+        ctx.save_for_backward(Kinv)
+        return capi.pixel2cam_fwd(_lib.get(), depth, Kinv)
+
+    @staticmethod
+    def backward(ctx, g_cam):
+        _no_grad_inputs(ctx, 1, ["intrinsics_inv"])
+        (Kinv,) = ctx.saved_tensors
+        return capi.pixel2cam_bwd(_lib.get(), Kinv, g_cam.contiguous()), None
+
+
+class Cam2Pixel(torch.autograd.Function):
+    """cam2pixel (inverse_warp.py:47-74) and cam2pixel2 (:194-227; ``overwrite`` = zeros padding, ``want_z``):
+    forward(flags, want_z, cam, rot | None, tr | None) -> grid [B,H,W,2] (, z [B,1,H,W])."""
+
+    @staticmethod
+    def forward(ctx, flags, want_z, cam, rot, tr):
+        cam = _c(cam)
+        rot = None if rot is None else _c(rot)
+        tr = None if tr is None else _c(tr)
+        _need_cuda(cam, rot, tr)
+        grid, z = capi.cam2pixel_fwd(_lib.get(), cam, rot, tr, flags, want_z)
+        ctx.flags, ctx.want_z = flags, want_z
+        ctx.has = (rot is not None, tr is not None)
+        ctx.save_for_backward(cam, *(t for t in (rot, tr) if t is not None))
+        ctx.set_materialize_grads(False)
+        return (grid, z) if want_z else grid
+
+    @staticmethod
+    def backward(ctx, g_grid, g_z=None):
+        saved = list(ctx.saved_tensors)
+        cam = saved.pop(0)
+        rot = saved.pop(0) if ctx.has[0] else None
+        tr = saved.pop(0) if ctx.has[1] else None
+        if g_grid is None:
+            g_grid = torch.zeros(cam.shape[0], cam.shape[2], cam.shape[3], 2, dtype=cam.dtype, device=cam.device)
+        cc = lambda t: None if t is None else t.contiguous()
+        g_cam, g_rot, g_tr = capi.cam2pixel_bwd(_lib.get(), cam, rot, tr, ctx.flags, cc(g_grid), cc(g_z))
+        return None, None, g_cam, g_rot if rot is not None else None, g_tr if tr is not None else None
 
 
 class PoseVec2Mat(torch.autograd.Function):

@@ -94,13 +94,22 @@ device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cp
 
 
 class _ScalarLog(object):
-    """Stand-in for tensorboardX.SummaryWriter (absent here): keeps the call sites, drops the data."""
+    """Stand-in for tensorboardX.SummaryWriter (train.py:85-89 of the reference; the package is absent here): keeps
+    the call sites and drops the data -- saying so once on stdout.  The two TSV logs (progress_log_*.csv) carry
+    the same scalars."""
+    _announced = False
+
+    def _announce(self):
+        if not _ScalarLog._announced:
+            _ScalarLog._announced = True
+            print("=> tensorboardX is not installed: TensorBoard scalars / images are not written "
+                  "(losses are in progress_log_full.csv and progress_log_summary.csv)")
 
     def add_scalar(self, *a, **k):
-        pass
+        self._announce()
 
     def add_image(self, *a, **k):
-        pass
+        self._announce()
 
 
 def build_datasets(args):

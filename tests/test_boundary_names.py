@@ -1,0 +1,45 @@
+"""The drop-in `inverse_warp` module exposes exactly the reference's namespace, and every name runs (CPU: kernels
+through tests/hostsim, fp64 against the oracle; the GPU twin is tests/test_gpu_parity.py::test_boundary_functions)."""
+import os
+
+import pytest
+import torch
+
+import _boundary_checks as BC
+
+REF = "/root/reference/inverse_warp.py"
+
+
+def test_star_import_exposes_the_reference_namespace():
+    ns = {}
+    exec("from inverse_warp import *", ns)
+    mine = {k for k in ns if not k.startswith("__")}
+    assert BC.REFERENCE_NAMES <= mine, BC.REFERENCE_NAMES - mine
+    # nothing of this package's plumbing leaks into the star import beyond what the reference's own would bring
+    assert mine == BC.REFERENCE_NAMES, mine ^ BC.REFERENCE_NAMES
+    if os.path.exists(REF):  # the list above is the reference's
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_ref_inverse_warp", REF)
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
+        assert {k for k in vars(ref) if not k.startswith("__")} == BC.REFERENCE_NAMES
+
+
+def test_every_public_name_runs_and_matches_the_oracle(monkeypatch):
+    import inverse_warp as IW
+    from hostsim import harness
+    from scsfm_hip import _lib, ops
+    lib = harness.lib()
+    monkeypatch.setattr(_lib, "get", lambda: lib)
+    monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)
+    BC.run(IW, torch.device("cpu"), torch.float64, 1e-12)
+    BC.run(IW, torch.device("cpu"), torch.float32, 2e-6)
+    # the remaining names
+    IW.set_id_grid(torch.zeros(1, 4, 5))
+    assert tuple(IW.pixel_coords.shape) == (1, 3, 4, 5)
+    ang = torch.tensor([[0.1, -0.2, 0.3]], dtype=torch.float64)
+    from oracle import scsfm_oracle as O
+    assert float((IW.euler2mat(ang) - O.rot_from_euler(ang)).abs().max()) < 1e-14
+    assert float((IW.quat2mat(ang) - O.rot_from_quat(ang)).abs().max()) < 1e-14
+    with pytest.raises(AssertionError, match="wrong size for depth"):
+        IW.pixel2cam(torch.zeros(2, 1, 4, 5), torch.zeros(2, 3, 3))

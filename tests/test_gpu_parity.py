@@ -134,14 +134,18 @@ def test_pose_and_errors_goldens(LF, IW, dev):
 # ------------------------------------------------------------------------------------------------
 # 2. the CPU oracle on seeded inputs, up to BASELINE.json's full size
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,H,W,n_ref,dataset,depth,auto", [
-    (2, 128, 416, 2, "kitti", "smooth", 0),
-    (2, 128, 416, 2, "kitti", "smooth", 1),
-    (3, 100, 210, 1, "kitti", "iid", 1),        # ragged: partial tiles
-    (12, 256, 832, 2, "kitti", "smooth", 1),    # configs[1] / [2] per-GPU workload
-    (4, 256, 320, 4, "nyu", "smooth", 1),       # configs[4]: NYU intrinsics, 4 refs
+@pytest.mark.parametrize("B,H,W,n_ref,dataset,depth,auto,pad,scales", [
+    (2, 128, 416, 2, "kitti", "smooth", 0, "zeros", 1),
+    (2, 128, 416, 2, "kitti", "smooth", 1, "zeros", 1),
+    (3, 100, 210, 1, "kitti", "iid", 1, "zeros", 1),        # ragged: partial tiles
+    (12, 256, 832, 2, "kitti", "smooth", 1, "zeros", 1),    # configs[1] / [2] per-GPU workload
+    (4, 256, 320, 4, "nyu", "smooth", 1, "zeros", 1),       # configs[4]: NYU intrinsics, 4 refs
+    (8, 256, 832, 2, "kitti", "smooth", 1, "zeros", 1),     # configs[3]: batch 8 per GPU
+    (4, 256, 832, 2, "kitti", "iid", 1, "zeros", 1),        # full size, incoherent gathers / scatter
+    (4, 256, 832, 2, "kitti", "smooth", 1, "border", 1),    # full size, border padding
+    (4, 256, 832, 1, "kitti", "smooth", 1, "zeros", 2),     # full size, two scales (--num-scales 2)
 ])
-def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto):
+def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto, pad, scales):
     """Losses to 1e-5 per pair term.  Gradients: the HIP fp32 result must be as close to the fp64
     oracle as the fp32 oracle (= the reference's own arithmetic) is, up to a factor, plus 0.5 % of the
     tensor's scale.  The factor matters for the pose gradients: with depths from 0.1 to 100 a handful
@@ -151,8 +155,8 @@ def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto):
     from oracle import scsfm_oracle as O
     from scsfm_hip import synth
     d = synth.make_batch(B, H, W, n_ref=n_ref, seed=17, depth=depth, image="smooth" if depth == "smooth" else "iid",
-                         dataset=dataset)
-    flags = (1, 1, auto, "zeros")
+                         dataset=dataset, num_scales=scales)
+    flags = (1, 1, auto, pad)
 
     def run(device, fn_pg, fn_s, dtype=torch.float32):
         mv = lambda t: t.to(device=device, dtype=dtype).clone().requires_grad_(True)
@@ -161,7 +165,7 @@ def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto):
         rd = [[mv(t) for t in r] for r in d["ref_depths"]]
         ps, pi = [mv(p) for p in d["poses"]], [mv(p) for p in d["poses_inv"]]
         tgt, refs, K = cv(d["tgt_img"]), [cv(r) for r in d["ref_imgs"]], cv(d["intrinsics"])
-        photo, geom = fn_pg(tgt, refs, K, td, rd, ps, pi, 1, *flags)
+        photo, geom = fn_pg(tgt, refs, K, td, rd, ps, pi, scales, *flags)
         smooth = fn_s(td, tgt, rd, refs)
         (photo + 0.1 * smooth + 0.5 * geom).backward()
         grads = [td[0].grad] + [r[0].grad for r in rd] + [p.grad for p in ps + pi]
@@ -171,7 +175,8 @@ def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto):
     vo, go = run("cpu", O.photo_and_geometry_loss, O.smooth_loss)
     v64, g64 = run("cpu", O.photo_and_geometry_loss, O.smooth_loss, torch.float64)
     for a, b, nm in zip(vh, vo, ("photo", "geom", "smooth")):
-        assert abs(a - b) <= 1e-5 * max(1, n_ref / 2), (nm, a, b)  # photo/geom are sums over 2*n_ref pair terms
+        # the bar is 1e-5 per compute_pairwise_loss term; photo / geom are sums over 2 * n_ref * scales of them
+        assert abs(a - b) <= 1e-5 * max(1, n_ref * scales / 2), (nm, a, b)
     for i, (a, b, c) in enumerate(zip(gh, go, g64)):
         scale = float(c.abs().max())
         if i <= n_ref:   # depth maps: entry-wise with a small share of outliers (flipped pixels)
@@ -179,7 +184,123 @@ def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto):
             assert bad <= 2e-3, (i, bad)
         else:            # poses: every entry, noise-aware
             ref_noise = (b - c).abs()
-            assert bool(((a - c).abs() <= POSE_RTOL * scale + 4 * ref_noise).all()), (i, a, b, c)
+            entrywise = bool(((a - c).abs() <= POSE_RTOL * scale + 4 * ref_noise).all())
+            # On incoherent (iid) inputs at full size the fp32 reference arithmetic itself is off by up to a quarter
+            # of the scale on single entries (measured: 0.093 of 0.389, variants/diag_iid.py) -- which entries depends
+            # on which near pixels' gates round the other way, so two fp32 implementations are off on DIFFERENT
+            # entries: also accept being no further from fp64 than 1.5 x the reference's own worst entry
+            tensorwise = float((a - c).abs().max()) <= POSE_RTOL * scale + 1.5 * float(ref_noise.max())
+            assert entrywise or tensorwise, (i, float((a - c).abs().max()), float(ref_noise.max()), scale)
+
+
+def test_forward_only_validation_path_against_oracle(LF, dev):
+    """validate_without_gt (train.py:302-362): torch.no_grad, auto-mask off -- the plain forward kernel (32 B/px),
+    no speculative backward -- at full size against the oracle."""
+    from oracle import scsfm_oracle as O
+    from scsfm_hip import synth
+    d = synth.make_batch(4, 256, 832, n_ref=2, seed=23, depth="smooth", image="smooth", dataset="kitti")
+    to = lambda t: t.to(dev)
+    with torch.no_grad():
+        photo, geom = LF.compute_photo_and_geometry_loss(to(d["tgt_img"]), [to(r) for r in d["ref_imgs"]], to(d["intrinsics"]),
+                                                         [to(t) for t in d["tgt_depth"]],
+                                                         [[to(t) for t in r] for r in d["ref_depths"]],
+                                                         [to(p) for p in d["poses"]], [to(p) for p in d["poses_inv"]],
+                                                         1, 1, 1, 0, "zeros")
+        smooth = LF.compute_smooth_loss([to(t) for t in d["tgt_depth"]], to(d["tgt_img"]),
+                                        [[to(t) for t in r] for r in d["ref_depths"]], [to(r) for r in d["ref_imgs"]])
+        po, go = O.photo_and_geometry_loss(d["tgt_img"], d["ref_imgs"], d["intrinsics"], d["tgt_depth"], d["ref_depths"],
+                                           d["poses"], d["poses_inv"], 1, 1, 1, 0, "zeros")
+        so = O.smooth_loss(d["tgt_depth"], d["tgt_img"], d["ref_depths"], d["ref_imgs"])
+    assert photo.grad_fn is None
+    assert abs(float(photo) - float(po)) <= 1e-5 and abs(float(geom) - float(go)) <= 1e-5 and abs(float(smooth) - float(so)) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# 2b. the fp64 instantiations of the SAME kernel sources on the hardware, against the fp64 oracle at 1e-9: what
+#     the CPU simulation checks for the logic (tiles, halos, wave shuffles, LDS parking, window atomics, last-block
+#     reductions) is checked here with real concurrency
+# ------------------------------------------------------------------------------------------------
+FLAGS8 = [(1, 1, 1), (1, 1, 0), (1, 0, 1), (1, 0, 0), (0, 1, 1), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
+
+
+def _rel64(a, b):
+    return float((a.cpu() - b).abs().max() / (b.abs().max() + 1e-300))
+
+
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+@pytest.mark.parametrize("flags3", FLAGS8)
+def test_fp64_pair_kernels_on_hardware(dev, flags3, pad):
+    """scsfm_pair_fwd_f64 + the two-pass backward (pair_bwd_photo / pair_bwd_geom), every flag combination."""
+    from oracle import scsfm_oracle as O
+    from scsfm_hip import _lib, capi, synth
+    lib = _lib.get()
+    d = synth.make_batch(2, 72, 100, n_ref=1, seed=21, depth="smooth")  # ragged: partial tiles on both axes
+    c = lambda x: x.double().contiguous()
+    host = [c(d["tgt_img"]), c(d["ref_imgs"][0]), c(d["tgt_depth"][0]), c(d["ref_depths"][0][0]), c(d["poses"][0]),
+            c(d["intrinsics"])]
+    ti, ri, td, rd, po, K = host
+    ssim, mask, auto = flags3
+    fl = capi.make_flags(ssim, mask, auto, pad)
+    out, ws = capi.pair_fwd(lib, *[t.to(dev) for t in host], fl)
+    tdl, rdl, pol = (t.clone().requires_grad_(True) for t in (td, rd, po))
+    diff_img, diff_depth, m = O.pairwise_maps(ti, ri, tdl, rdl, pol, K, ssim, mask, auto, pad)
+    assert abs(float(out[4]) - float(m.sum())) == 0
+    assert abs(float(out[2]) - float((diff_img * m).sum().detach())) < 1e-9
+    assert abs(float(out[3]) - float((diff_depth * m).sum().detach())) < 1e-9
+    Sm = m.sum()
+    gate_g = 1.0 if float(Sm) > 10000 else 0.0
+    (0.7 * (diff_img * m).sum() / (3 * Sm) + gate_g * 1.3 * (diff_depth * m).sum() / Sm).backward()
+    t = lambda v: torch.tensor([v], dtype=torch.float64, device=dev)
+    gt, gr, gp = capi.pair_bwd(lib, *[x.to(dev) for x in host], fl, ws, t(0.7), t(1.3))
+    assert _rel64(gt, tdl.grad) < 1e-9 and _rel64(gp, pol.grad) < 1e-9
+    if rdl.grad is not None and float(rdl.grad.abs().max()) > 0:
+        assert _rel64(gr, rdl.grad) < 1e-9
+
+
+@pytest.mark.parametrize("H,W,B", [(72, 100, 2), (15, 63, 40), (33, 129, 8), (5, 200, 40)])
+@pytest.mark.parametrize("hint,upstream", [((0.7, 1.3), (0.7, 1.3)),   # speculation holds
+                                           ((0.7, 1.3), (1.0, 0.5)),   # wrong hint: device-side fallback
+                                           (None, (0.7, 1.3))])        # plain forward
+def test_fp64_speculative_forward_on_hardware(dev, H, W, B, hint, upstream):
+    """scsfm_pairs_fwd_f64 / scsfm_pairs_bwd_f64: the fused speculative forward (+ combine), the fallback passes
+    behind their guards and the plain path, at sizes that are no multiple of any tile."""
+    from oracle import scsfm_oracle as O
+    from scsfm_hip import _lib, capi, synth
+    lib = _lib.get()
+    d = synth.make_batch(B, H, W, n_ref=2, seed=H * 100 + W, depth="smooth")
+    c = lambda x: x.double().contiguous()
+    ti, K = c(d["tgt_img"]), c(d["intrinsics"])
+    ris = [c(r) for r in d["ref_imgs"]]
+    tds, rds = [c(d["tgt_depth"][0])], [[c(r[0])] for r in d["ref_depths"]]
+    ps, pis = [c(p) for p in d["poses"]], [c(p) for p in d["poses_inv"]]
+    lf = lambda x: x.clone().requires_grad_(True)
+    td, rd = [lf(t) for t in tds], [[lf(t) for t in r] for r in rds]
+    pp, pi = [lf(p) for p in ps], [lf(p) for p in pis]
+    po, go = O.photo_and_geometry_loss(ti, ris, K, td, rd, pp, pi, 1, 1, 1, 1, "zeros")
+    (upstream[0] * po + upstream[1] * go).backward()
+    g = lambda x: x.to(dev)
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    dv = dict(ti=g(ti), K=g(K), ris=[g(r) for r in ris], tds=[g(t) for t in tds], rds=[[g(t) for t in r] for r in rds],
+              ps=[g(p) for p in ps], pis=[g(p) for p in pis])
+    photo, geom, _, ws = capi.photo_geometry_fwd(lib, fl, dv["ti"], dv["K"], dv["ris"], dv["tds"], dv["rds"], dv["ps"],
+                                                 dv["pis"], hint=hint)
+    assert abs(float(photo) - float(po)) < 1e-11 and abs(float(geom) - float(go)) < 1e-11
+    t = lambda v: torch.tensor([v], dtype=torch.float64, device=dev)
+    g_td, g_rd, g_p, g_pi = capi.photo_geometry_bwd(lib, fl, dv["ti"], dv["K"], dv["ris"], dv["tds"], dv["rds"], dv["ps"],
+                                                    dv["pis"], ws, t(upstream[0]), t(upstream[1]))
+    z = lambda x: x.grad if x.grad is not None else torch.zeros_like(x)
+    assert _rel64(g_td[0], z(td[0])) < 1e-9
+    for i in range(2):
+        assert _rel64(g_rd[i][0], z(rd[i][0])) < 1e-9
+        assert _rel64(g_p[i], z(pp[i])) < 1e-9 and _rel64(g_pi[i], z(pi[i])) < 1e-9
+
+
+def test_boundary_functions(IW, dev):
+    """pixel2cam / cam2pixel / cam2pixel2 / legacy inverse_warp (euler and quat) on the hardware, fp64 and fp32,
+    values and gradients against the oracle (tests/_boundary_checks.py; CPU twin: tests/test_boundary_names.py)."""
+    import _boundary_checks as BC
+    BC.run(IW, dev, torch.float64, 1e-12)
+    BC.run(IW, dev, torch.float32, 2e-6)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -117,3 +117,29 @@ def test_dataset_tree_and_transforms(tmp_path):
         if K1[0, 2] != K0[0, 2]:
             assert K1[0, 2] == 64 - 30
             break
+
+
+def test_pair_folder_follows_the_reference_layout(tmp_path):
+    """datasets/pair_folders.py:33-45 of the reference: sorted frames, pair k = frames (2k, 2k+1) in that order with the
+    k-th intrinsics file of the scene; never swapped."""
+    from PIL import Image
+    from datasets.pair_folders import PairFolder
+    scene = tmp_path / "s0"
+    scene.mkdir()
+    for k in range(3):
+        for j in range(2):
+            Image.fromarray(np.full((8, 12, 3), 40 * k + 10 * j, dtype=np.uint8)).save(scene / f"{k:04d}_{j}.jpg", quality=100)
+        np.savetxt(scene / f"{k:04d}_cam.txt", np.array([[100.0 + k, 0, 6], [0, 100.0 + k, 4], [0, 0, 1]]))
+    Image.fromarray(np.zeros((8, 12, 3), dtype=np.uint8)).save(scene / "9999_0.jpg")  # unpaired trailing frame: ignored
+    (tmp_path / "train.txt").write_text("s0\n")
+    ds = PairFolder(str(tmp_path), seed=0, train=True, transform=None)
+    assert len(ds) == 3
+    seen = set()
+    for i in range(3):
+        tgt, refs, K, Kinv = ds[i]
+        k = int(round(float(K[0, 0]) - 100.0))
+        seen.add(k)
+        assert len(refs) == 1
+        assert abs(float(tgt.mean()) - 40 * k) < 3 and abs(float(refs[0].mean()) - (40 * k + 10)) < 3  # (0 then 1, fixed)
+        np.testing.assert_allclose(K @ Kinv, np.eye(3), atol=1e-5)
+    assert seen == {0, 1, 2}
