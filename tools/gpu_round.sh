@@ -12,9 +12,9 @@ echo "=== smoke"; python __graft_entry__.py --smoke > $O/smoke_$TAG.log 2>&1; ec
 echo "=== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu_$TAG.log
 echo "=== bench"; timeout 900 python bench.py --steps 50 --warmup 10 > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc=$?"; cut -c1-2600 $O/bench_$TAG.json; tail -2 $O/bench_$TAG.err
 echo "=== bench iid"; timeout 600 python bench.py --loss-steps 30 --loss-warmup 5 --depth iid --cpu-seconds 0 --e2e 0 > $O/bench_${TAG}_iid.json 2>> $O/bench_$TAG.err; cut -c1-400 $O/bench_${TAG}_iid.json
-echo "=== bench configs[3] loss path (batch 8) and configs[4] (NYU 256x320, 4 refs, batch 16)"
-timeout 600 python bench.py --loss-steps 30 --loss-warmup 5 --batch 8 --cpu-seconds 0 --e2e 0 > $O/bench_${TAG}_cfg3.json 2>> $O/bench_$TAG.err; cut -c1-330 $O/bench_${TAG}_cfg3.json
-timeout 600 python bench.py --loss-steps 30 --loss-warmup 5 --dataset nyu --height 256 --width 320 --n-ref 4 --batch 16 --cpu-seconds 0 --e2e 0 > $O/bench_${TAG}_cfg4.json 2>> $O/bench_$TAG.err; cut -c1-330 $O/bench_${TAG}_cfg4.json
+echo "=== bench configs[3] (ResNet50 encoder, batch 8 per GPU) and configs[4] (NYU 256x320, sequence length 5, batch 16): whole training step + loss path"
+timeout 900 python bench.py --steps 10 --warmup 3 --resnet-layers 50 --batch 8 --loss-steps 30 --loss-warmup 5 --cpu-seconds 0 > $O/bench_${TAG}_cfg3.json 2>> $O/bench_$TAG.err; cut -c1-420 $O/bench_${TAG}_cfg3.json
+timeout 900 python bench.py --steps 10 --warmup 3 --dataset nyu --height 256 --width 320 --n-ref 4 --batch 16 --loss-steps 30 --loss-warmup 5 --cpu-seconds 0 > $O/bench_${TAG}_cfg4.json 2>> $O/bench_$TAG.err; cut -c1-420 $O/bench_${TAG}_cfg4.json
 cd /tmp
 echo "=== rocprof kernel trace"; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --loss-steps 20 --loss-warmup 5 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 3 > $O/rocprof_$TAG.log 2>&1; echo "rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -22,3 +22,4 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 python tools/rocprof_summary.py $O/prof_$TAG/trace_results.db | grep -v "at::native\|rocclr" | head -20
+bash tools/gpu_sq.sh $TAG > $O/sq_$TAG.txt 2>&1; tail -14 $O/sq_$TAG.txt
