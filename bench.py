@@ -459,13 +459,18 @@ def main():
     kernel_sum = kt["pairs_fwd_spec"] + kt["pairs_bwd_after_spec"] + kt["smooth_fwd"] + kt["smooth_bwd"]
 
     if rank == 0:
-        workload = (f"configs[1]: {args.dataset} {args.height}x{args.width}, batch {args.batch}/GPU, {args.n_ref} refs "
+        shape = (args.dataset, args.height, args.width, args.batch, args.n_ref, args.resnet_layers)
+        # which BASELINE.json config this run is the per-GPU workload of ([1] and [2] share theirs)
+        named = {("kitti", 256, 832, 12, 2, 18): "configs[1]", ("kitti", 256, 832, 8, 2, 50): "configs[3]",
+                 ("nyu", 256, 320, 16, 4, 18): "configs[4] (batch 16/GPU)", ("kitti", 256, 832, 4, 2, 18): "configs[0] shape"}
+        workload = (f"{named.get(shape, 'custom')}: {args.dataset} {args.height}x{args.width}, batch {args.batch}/GPU, {args.n_ref} refs "
                     f"(seq {args.n_ref + 1}), ResNet{args.resnet_layers} DispNet + ResNet18 PoseNet, ssim+mask+auto-mask, "
                     f"zeros padding, 1 scale")
         if e2e is not None:
             value = world * args.batch * args.steps / e2e["elapsed_s"]
             ms_per_step = e2e["elapsed_s"] / args.steps * 1e3
-            metric = "train images/sec (+ warp-loss ms/step) KITTI 256x832 RN18"
+            metric = "train images/sec (+ warp-loss ms/step) KITTI 256x832 RN18" if shape[:3] == ("kitti", 256, 832) and \
+                args.resnet_layers == 18 else f"train images/sec (+ warp-loss ms/step) {args.dataset} {args.height}x{args.width} RN{args.resnet_layers}"
             parallelism = (f"ddp{world}: one process per GPU, DistributedDataParallel, bucketed {backend} all-reduce of "
                            f"{e2e['trainable_parameters'] * 4 / 1e6:.1f} MB of fp32 gradients per step; loss path sharded "
                            f"by batch, no loss-path collective") if world > 1 else "1 GPU"

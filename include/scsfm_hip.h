@@ -60,7 +60,7 @@ extern "C" {
 /* ABI version of this header; bumped on any change of a signature or of what an entry point does with its
  * buffers (2: the batched backwards store their depth gradients; scratch holds six planes.  3: scsfm_smooth_multi_bwd
  * takes `accumulate`; scsfm_step_total / scsfm_step_weights; scsfm_pair_desc::total.  4: scsfm_pixel2cam_*, scsfm_cam2pixel_*,
- * SCSFM_ROT_QUAT_FLAG for the warp entry points). */
+ * SCSFM_ROT_QUAT_FLAG for the warp entry points.  5: scsfm_pair_desc::depth_shift). */
 int scsfm_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -154,6 +154,10 @@ typedef struct scsfm_pair_desc {
   void* total; /* read from d[0] only, may be NULL: 2 elements (device, store) that the forward fills with the
                   sums over all n pair-directions of out[0] (photo) and out[1] (geometry) -- what
                   compute_photo_and_geometry_loss returns (loss_functions.py:89-92) -- without a launch of its own */
+  int depth_shift; /* 0: tgt_depth / ref_depth (and their gradient buffers) are [B,1,H,W].  s > 0: they are the maps of
+                      a coarser scale, [B,1,H>>s,W>>s] with H, W multiples of 2^s, and the kernels read them through
+                      the index map of F.interpolate(..., (H, W), mode='nearest') (loss_functions.py:77-82) instead of a
+                      materialised up-sampled copy; g_tgt_depth / g_ref_depth receive the sum-pooled gradients */
 } scsfm_pair_desc;
 
 int scsfm_pairs_fwd_f32(int n, const scsfm_pair_desc* d, int B, int H, int W, const float* intrinsics,

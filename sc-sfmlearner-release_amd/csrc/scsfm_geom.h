@@ -272,6 +272,44 @@ __device__ __forceinline__ TapRows<T> load_tap_rows(const T* __restrict__ plane,
   r.s = ld_at(reinterpret_cast<const TapPair<T>*>(plane), s.offr[1] * unsigned(sizeof(T)));
   return r;
 }
+// A depth map as the pair kernels read it.  Full resolution: the [H, W] plane.  kScaled (kernels instantiated for
+// multi-scale steps): the map of a coarser scale, [H >> ds, W >> ds], whose nearest up-sampling to (H, W)
+// (loss_functions.py:77-82: F.interpolate(..., mode='nearest') of every scale before compute_pairwise_loss) is
+// folded into the index: for H, W multiples of 2^ds the up-sampled map is map[y >> ds][x >> ds].  ds is a property
+// of the pair (uniform over a workgroup; 0 for the scale-0 pairs of the same launch).  The full-resolution
+// instantiation carries none of this: same addresses and loads as before the scaled one existed.
+template <typename T, bool kScaled>
+struct DepthMap {
+  const T* __restrict__ p;
+  int ds;
+  unsigned wl;  // row length of the stored map = W >> ds
+  // full_off: byte offset of (x, y) in a full-resolution plane (the caller has it for the colour planes anyway)
+  __device__ __forceinline__ T at(int x, int y, unsigned full_off) const {
+    if (!kScaled) return ld_at(p, full_off);
+    return ld_at(p, ((unsigned(y) >> ds) * wl + (unsigned(x) >> ds)) * unsigned(sizeof(T)));
+  }
+  // the 2 x 2 block a sample reads: two 8-byte loads at full resolution, four scalar loads through the index map
+  __device__ __forceinline__ TapRows<T> taps(const Sample<T>& s) const {
+    if (!kScaled || ds == 0) return load_tap_rows(p, s);
+    TapRows<T> r;
+    const unsigned xa = unsigned(s.xa) >> ds, xb = unsigned(s.xa + 1) >> ds;
+    const unsigned ra = (unsigned(s.ya) >> ds) * wl, rb = (unsigned(s.ya + 1) >> ds) * wl;
+    r.n.a = ld_at(p, (ra + xa) * unsigned(sizeof(T)));
+    r.n.b = ld_at(p, (ra + xb) * unsigned(sizeof(T)));
+    r.s.a = ld_at(p, (rb + xa) * unsigned(sizeof(T)));
+    r.s.b = ld_at(p, (rb + xb) * unsigned(sizeof(T)));
+    return r;
+  }
+};
+template <bool kScaled, typename T>
+__device__ __forceinline__ DepthMap<T, kScaled> depth_map(const T* maps, int b, int H, int W, int ds) {
+  DepthMap<T, kScaled> m;
+  m.ds = kScaled ? ds : 0;
+  m.wl = unsigned(W) >> m.ds;
+  m.p = maps + (size_t)b * ((unsigned(H) >> m.ds) * m.wl);
+  return m;
+}
+
 // The sampled value.
 template <typename T>
 __device__ __forceinline__ T bilerp_rows(const TapRows<T>& r, const Sample<T>& s) {
@@ -409,11 +447,12 @@ __device__ __forceinline__ void flush_scatter_region(const Cell (*win)[WW], int 
 // Where the window of a tile sits: centred on where the tile's centre pixel (ax, ay) lands in the reference
 // view.  Every thread evaluates it (one broadcast load + one projection): handing it over from a single
 // thread would put that thread's dependent load in front of a barrier for the whole block.
-template <typename T, int WW, int WH>
-__device__ __forceinline__ void window_origin(const BatchConsts<T>& bc, int ax, int ay, const T* __restrict__ tgt_depth,
+template <typename T, int WW, int WH, typename Map>
+__device__ __forceinline__ void window_origin(const BatchConsts<T>& bc, int ax, int ay, const Map& tgt_depth,
                                               int H, int W, unsigned flags, int& wx0, int& wy0) {
   ax = t_clampi(ax, 0, W - 1); ay = t_clampi(ay, 0, H - 1);
-  const Sample<T> sc = project_pixel(bc, ax, ay, tgt_depth[unsigned(ay) * unsigned(W) + unsigned(ax)], H, W, flags);
+  const unsigned off = (unsigned(ay) * unsigned(W) + unsigned(ax)) * unsigned(sizeof(T));
+  const Sample<T> sc = project_pixel(bc, ax, ay, tgt_depth.at(ax, ay, off), H, W, flags);
   wx0 = sc.xa - WW / 2;
   wy0 = sc.ya - WH / 2;
 }
@@ -425,16 +464,16 @@ __device__ __forceinline__ void window_origin(const BatchConsts<T>& bc, int ax, 
 // returns dL/d tgt_depth(p).  g_dd = dL/d diff_depth(p).
 // (Measured alternatives, both slower: a software pipeline that requests pixel r + 1's taps before pixel r is
 // consumed, and finishing the whole strip's arithmetic before a separate scatter loop over compact records.)
-template <typename T, typename Cell, int WW, int WH>
+template <typename T, typename Cell, int WW, int WH, typename Map>
 __device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py, T d, const T (&gI)[3], T g_dd,
-                                        const T* __restrict__ ref_img, const T* __restrict__ ref_depth,
+                                        const T* __restrict__ ref_img, const Map& ref_depth,
                                         unsigned plane, int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
                                         T* __restrict__ scatter_plane, T* acc) {
   const Sample<T> s = project_pixel(bc, px, py, d, H, W, flags);
   TapRows<T> tc[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) tc[c] = load_tap_rows(ref_img + c * plane, s);
-  const TapRows<T> td = load_tap_rows(ref_depth, s);
+  const TapRows<T> td = ref_depth.taps(s);
   const T Dp = bilerp_rows(td, s);
   const T diff = s.Z - Dp, sum = s.Z + Dp;
   const T isum = t_rcp(sum);

@@ -39,6 +39,7 @@ struct PairArgs {
   const T* tgt_img; const T* ref_img; const T* tgt_depth; const T* ref_depth; const T* pose;
   BatchConsts<T>* consts; double* sums; double* partials; double* gPp;
   T* out; T* gbuf; T* g_ref_depth; T* g_pose;
+  int ds;  // log2 of the down-scale of BOTH depth maps of this pair (scsfm_pair_desc::depth_shift)
 };
 constexpr int kMaxPairs = 8;
 // Planes of a pair's gbuf (each B x H x W): what the tiled pass hands to the geometry pass, and the geometry
@@ -58,12 +59,12 @@ struct PairBatch {
 // The streaming inputs of one pixel (already reflected into the image): depth, target colours and -- for
 // the auto-mask -- the un-warped reference colours.  They are loaded for a thread's whole strip before
 // anything else, so that a single memory round trip precedes the dependent gathers.
-template <typename T>
+template <typename T, typename Map>
 __device__ __forceinline__ void load_pixel(int u, int v, int W, unsigned plane, const T* __restrict__ tgt_img,
-                                           const T* __restrict__ ref_img, const T* __restrict__ tgt_depth,
+                                           const T* __restrict__ ref_img, const Map& tgt_depth,
                                            bool with_ref, T& depth, T (&tgt)[3], T (&ref)[3]) {
   const unsigned off = (unsigned(v) * unsigned(W) + unsigned(u)) * unsigned(sizeof(T));
-  depth = ld_at(tgt_depth, off);
+  depth = tgt_depth.at(u, v, off);
 #pragma unroll
   for (int c = 0; c < 3; ++c) tgt[c] = ld_at(tgt_img + c * plane, off);
 #pragma unroll
@@ -121,15 +122,13 @@ __device__ __forceinline__ T pixel_mask(const Sample<T>& s, bool with_auto, cons
 // ==========================================================================================
 // Forward
 // ==========================================================================================
-template <typename T, bool kSsim>
+template <typename T, bool kSsim, bool kScaled>
 __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(PairBatch<T> pb, int B, int H, int W, unsigned flags) {
   const BlockId blk = xcd_block_id();
   const int pair = blk.z / B, b = blk.z - pair * B;
   const PairArgs<T>& pa = pb.p[pair];
   const T* __restrict__ tgt_img = pa.tgt_img;
   const T* __restrict__ ref_img = pa.ref_img;
-  const T* __restrict__ tgt_depth = pa.tgt_depth;
-  const T* __restrict__ ref_depth = pa.ref_depth;
   const BatchConsts<T>* __restrict__ consts = pa.consts;
   double* __restrict__ partials = pa.partials;
   typedef typename Vec2<T>::type V2;
@@ -144,8 +143,8 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(PairBatch<T> pb, int
   const unsigned plane = unsigned(H) * unsigned(W);
   tgt_img += (size_t)b * 3 * plane;
   ref_img += (size_t)b * 3 * plane;
-  tgt_depth += (size_t)b * plane;
-  ref_depth += (size_t)b * plane;
+  const DepthMap<T, kScaled> tgt_depth = depth_map<kScaled>(pa.tgt_depth, b, H, W, pa.ds);
+  const DepthMap<T, kScaled> ref_depth = depth_map<kScaled>(pa.ref_depth, b, H, W, pa.ds);
 
   T m[STRIP], dd[STRIP], l1sum[STRIP];
   // ---- phase 0: every streaming load of the strip and of this thread's ring pixel ---------------
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(PairBatch<T> pb, int
     }
     l1sum[k] = clamp01(t_abs(xy[0][0] - xy[0][1])) + clamp01(t_abs(xy[1][0] - xy[1][1])) +
                clamp01(t_abs(xy[2][0] - xy[2][1]));  // loss_functions.py:99, summed over colours
-    const T Dp = bilerp_rows(load_tap_rows(ref_depth, s), s);
+    const T Dp = bilerp_rows(ref_depth.taps(s), s);
     dd[k] = clamp01(t_abs(s.Z - Dp) * t_rcp(s.Z + Dp));  // loss_functions.py:101
     m[k] = inimg ? pixel_mask(s, with_auto, xy, in_r[k]) : T(0);
   }
@@ -344,7 +343,7 @@ constexpr unsigned kTrainFlags = SCSFM_WITH_SSIM | SCSFM_WITH_MASK | SCSFM_WITH_
 #include "scsfm_strip.h"  // the speculative forward proper (needs PairArgs / PairBatch / the plane indices above)
 namespace scsfm {
 
-template <typename T, bool kSsim, bool kSpec, unsigned kFlags = kRuntimeFlags>
+template <typename T, bool kSsim, bool kSpec, bool kScaled, unsigned kFlags = kRuntimeFlags>
 __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, const PairBatch<T>& pb, int B, int H,
                                            int W, unsigned flags_arg, const T* __restrict__ g_photo,
                                            const T* __restrict__ g_geom, T r_hint) {
@@ -353,8 +352,6 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
   const PairArgs<T>& pa = pb.p[pair];
   const T* __restrict__ tgt_img = pa.tgt_img;
   const T* __restrict__ ref_img = pa.ref_img;
-  const T* __restrict__ tgt_depth = pa.tgt_depth;
-  const T* __restrict__ ref_depth = pa.ref_depth;
   const BatchConsts<T>* __restrict__ consts = pa.consts;
   const double* __restrict__ sums = pa.sums;
   T* __restrict__ gbuf = pa.gbuf;
@@ -390,8 +387,8 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
   const size_t gplane = (size_t)B * plane;  // one gbuf plane spans the whole batch
   tgt_img += (size_t)b * 3 * plane;
   ref_img += (size_t)b * 3 * plane;
-  tgt_depth += (size_t)b * plane;
-  ref_depth += (size_t)b * plane;
+  const DepthMap<T, kScaled> tgt_depth = depth_map<kScaled>(pa.tgt_depth, b, H, W, pa.ds);
+  const DepthMap<T, kScaled> ref_depth = depth_map<kScaled>(pa.ref_depth, b, H, W, pa.ds);
   gbuf += (size_t)b * plane;
 
   const int px = ox + col, py0 = oy + strip * STRIP;
@@ -434,7 +431,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
     for (int c = 0; c < 3; ++c) {
       if constexpr (kSsim) sXY[c][ly + 1][col + 1] = xy[c]; else cen[k][c] = xy[c];
     }
-    const T Dp = bilerp_rows(load_tap_rows(ref_depth, s), s);
+    const T Dp = bilerp_rows(ref_depth.taps(s), s);
     const T ddk = clamp01(t_abs(s.Z - Dp) * t_rcp(s.Z + Dp));
     mq[k] = inimg ? pixel_mask(s, with_auto, xy, in_r[k]) : T(0);
     coef[k] = a * mq[k] * (with_mask ? (T(1) - ddk) : T(1));
@@ -608,17 +605,17 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
 }
 
 // The speculative forward: one tile per workgroup, XCD-aware order.
-template <typename T, bool kSsim, unsigned kFlags = kRuntimeFlags>
+template <typename T, bool kSsim, unsigned kFlags = kRuntimeFlags, bool kScaled = false>
 __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) void pair_fwd_spec_kernel(PairBatch<T> pb, int B, int H, int W,
                                                                                   unsigned flags, T r_hint) {
-  photo_tile<T, kSsim, true, kFlags>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, pb, B, H, W, flags, nullptr, nullptr,
+  photo_tile<T, kSsim, true, kScaled, kFlags>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, pb, B, H, W, flags, nullptr, nullptr,
                                      r_hint);
 }
 
 // Pass A of the backward.  Launched with a small persistent grid that walks the tiles: when the speculative
 // forward's results stand (the usual case) every tile returns at once and the launch costs ~1 us instead of
 // the ~12 us of ten thousand empty workgroups.
-template <typename T, bool kSsim>
+template <typename T, bool kSsim, bool kScaled>
 __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) void pair_bwd_photo_kernel(
     PairBatch<T> pb, int nbx, int nby, int nz, int B, int H, int W, unsigned flags, const T* __restrict__ g_photo,
     const T* __restrict__ g_geom) {
@@ -628,7 +625,7 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) 
   for (int t = blockIdx.x; t < n; t += gridDim.x) {
     const BlockId blk = xcd_tile_of(t, nbx, nby, nz);
     if (!((live >> (blk.z / B)) & 1u)) continue;
-    photo_tile<T, kSsim, false>(blk, nbx, nby, pb, B, H, W, flags, g_photo, g_geom, T(0));
+    photo_tile<T, kSsim, false, kScaled>(blk, nbx, nby, pb, B, H, W, flags, g_photo, g_geom, T(0));
     __syncthreads();  // the tile's LDS is reused
   }
 }
@@ -642,14 +639,12 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) 
 #ifndef SCSFM_GEOM_BLOCKS  // tuning knob: workgroups per CU the geometry pass is compiled for
 #define SCSFM_GEOM_BLOCKS 4
 #endif
-template <typename T>
+template <typename T, bool kScaled>
 __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, const PairBatch<T>& pb, int B, int H, int W,
                                           unsigned flags, const T* __restrict__ g_photo, const T* __restrict__ g_geom) {
   const int pair = blk.z / B, b = blk.z - pair * B;
   const PairArgs<T>& pa = pb.p[pair];
   const T* __restrict__ ref_img = pa.ref_img;
-  const T* __restrict__ tgt_depth = pa.tgt_depth;
-  const T* __restrict__ ref_depth = pa.ref_depth;
   const BatchConsts<T>* __restrict__ consts = pa.consts;
   const double* __restrict__ sums = pa.sums;
   const T* __restrict__ gbuf = pa.gbuf;
@@ -668,8 +663,8 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
   const unsigned plane = unsigned(H) * unsigned(W);
   const size_t gplane = (size_t)B * plane;
   ref_img += (size_t)b * 3 * plane;
-  tgt_depth += (size_t)b * plane;
-  ref_depth += (size_t)b * plane;
+  const DepthMap<T, kScaled> tgt_depth = depth_map<kScaled>(pa.tgt_depth, b, H, W, pa.ds);
+  const DepthMap<T, kScaled> ref_depth = depth_map<kScaled>(pa.ref_depth, b, H, W, pa.ds);
   gbuf += (size_t)b * plane;
   // both outputs go to private planes of this pair's gbuf (dense: plain stores; scatter: atomics into the plane
   // pass A zeroed); pairs_combine_kernel adds them to the callers' buffers.  That keeps every pair-direction of
@@ -690,8 +685,9 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     const int py = py0 + r;
-    const unsigned p = (unsigned(py < H ? py : H - 1) * unsigned(W) + unsigned(px < W ? px : W - 1)) * unsigned(sizeof(T));
-    in_d[r] = ld_at(tgt_depth, p);
+    const int cy = py < H ? py : H - 1, cx = px < W ? px : W - 1;
+    const unsigned p = (unsigned(cy) * unsigned(W) + unsigned(cx)) * unsigned(sizeof(T));
+    in_d[r] = tgt_depth.at(cx, cy, p);
 #pragma unroll
     for (int c = 0; c < 3; ++c) in_g[r][c] = ld_at(gbuf + (kPlaneGI + c) * gplane, p);
     in_g[r][3] = ld_at(gbuf + kPlaneGdd * gplane, p);
@@ -723,7 +719,7 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
 // Persistent grid over the tiles, natural order (with the XCD-contiguous order of the tiled kernels this pass
 // measured 2 % slower: its scatter / flush atomics then hit one image's lines from a single XCD at a time).
 // Like pass A it returns at once per tile when the speculative forward's results stand.
-template <typename T>
+template <typename T, bool kScaled>
 __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_GEOM_BLOCKS : 1) void pair_bwd_geom_kernel(
     PairBatch<T> pb, int nbx, int nby, int nz, int B, int H, int W, unsigned flags, const T* __restrict__ g_photo,
     const T* __restrict__ g_geom) {
@@ -737,7 +733,7 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_GEOM_BLOCKS : 1) v
     blk.y = q % nby;
     blk.z = q / nby;
     if (!((live >> (blk.z / B)) & 1u)) continue;
-    geom_tile<T>(blk, nbx, nby, pb, B, H, W, flags, g_photo, g_geom);
+    geom_tile<T, kScaled>(blk, nbx, nby, pb, B, H, W, flags, g_photo, g_geom);
     __syncthreads();  // the window is reused
   }
 }
@@ -791,12 +787,34 @@ template <typename T>
 struct CombineBatch {
   T* dst[2 * kMaxPairs];
   int store[2 * kMaxPairs];  // 1: dst = sum (the first time a call touches this buffer), 0: dst += sum
+  int ds[2 * kMaxPairs];     // dst is the gradient of a [H >> ds, W >> ds] map: the planes are sum-pooled into it
   int nd, nsrc;
   CombineSrc<T> src[2 * kMaxPairs];
 };
 
 template <typename T>
 struct alignas(16) Quad { T v[16 / sizeof(T)]; };  // 16-byte vector access
+
+// This destination's sources, with the factor each still lacks (0: nothing to add).
+template <typename T>
+__device__ __forceinline__ bool combine_sources(const CombineBatch<T>& cb, int d, const T* __restrict__ g_photo,
+                                                const T* __restrict__ g_geom, const T* (&src)[2 * kMaxPairs],
+                                                T (&scale)[2 * kMaxPairs]) {
+  bool aligned = (reinterpret_cast<size_t>(cb.dst[d]) & 15) == 0;
+#pragma unroll
+  for (int k = 0; k < 2 * kMaxPairs; ++k) {
+    src[k] = nullptr;
+    scale[k] = T(0);
+    if (k < cb.nsrc && cb.src[k].dst == d) {
+      const double* s = cb.src[k].sums;
+      const bool live = !(T(s[5]) * g_photo[0] == T(0) && T(s[6]) * g_geom[0] == T(0));
+      src[k] = cb.src[k].plane;
+      scale[k] = live ? pair_scale(s, g_photo, g_geom) : T(0);
+      aligned = aligned && (reinterpret_cast<size_t>(src[k]) & 15) == 0;
+    }
+  }
+  return aligned;
+}
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T> cb, size_t n, PairBatch<T> pb, int npairs,
@@ -818,25 +836,13 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
     }
     return;
   }
+  if (cb.ds[d]) return;  // a coarser scale's map: pairs_combine_pooled_kernel
   constexpr int Q = 16 / sizeof(T);
   T* __restrict__ dst = cb.dst[d];
   const bool store = cb.store[d] != 0;
-  // this destination's sources, with the factor each still lacks (0: nothing to add)
   const T* src[2 * kMaxPairs];
   T scale[2 * kMaxPairs];
-  bool aligned = (reinterpret_cast<size_t>(dst) & 15) == 0;
-#pragma unroll
-  for (int k = 0; k < 2 * kMaxPairs; ++k) {
-    src[k] = nullptr;
-    scale[k] = T(0);
-    if (k < cb.nsrc && cb.src[k].dst == d) {
-      const double* s = cb.src[k].sums;
-      const bool live = !(T(s[5]) * g_photo[0] == T(0) && T(s[6]) * g_geom[0] == T(0));
-      src[k] = cb.src[k].plane;
-      scale[k] = live ? pair_scale(s, g_photo, g_geom) : T(0);
-      aligned = aligned && (reinterpret_cast<size_t>(src[k]) & 15) == 0;
-    }
-  }
+  const bool aligned = combine_sources(cb, d, g_photo, g_geom, src, scale);
   // 16-byte accesses over the part every plane has 16-byte aligned (n is a multiple of Q for every image size
   // in use; the scalar loop below takes whatever is left)
   const size_t nq = aligned ? n / Q : 0;
@@ -864,6 +870,42 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
 #pragma unroll
     for (int k = 0; k < 2 * kMaxPairs; ++k)
       if (scale[k] != T(0)) acc += scale[k] * src[k][i];
+    dst[i] = store ? acc : dst[i] + acc;
+  }
+}
+
+// The destinations of a CombineBatch that are gradients of a coarser scale's map ([B, H >> ds, W >> ds]): the backward
+// of the nearest up-sampling (loss_functions.py:77-82) is the sum over each 2^ds x 2^ds block of the full-resolution
+// planes.  Launched only when a call has such destinations.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pairs_combine_pooled_kernel(CombineBatch<T> cb, size_t n, int W,
+                                                                        const T* __restrict__ g_photo,
+                                                                        const T* __restrict__ g_geom) {
+  const int d = (int)blockIdx.y;
+  const int ds = cb.ds[d];
+  if (!ds) return;
+  T* __restrict__ dst = cb.dst[d];
+  const bool store = cb.store[d] != 0;
+  const T* src[2 * kMaxPairs];
+  T scale[2 * kMaxPairs];
+  (void)combine_sources(cb, d, g_photo, g_geom, src, scale);
+  // row r of the map (over batch and rows: H is a multiple of 2^ds) covers the full-resolution rows from r << ds
+  const unsigned wl = unsigned(W) >> ds, side = 1u << ds;
+  const size_t nl = n >> (2 * ds);
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nl; i += (size_t)gridDim.x * kThreads) {
+    const size_t r = i / wl;
+    const unsigned xl = unsigned(i - r * wl);
+    const size_t base = (r << ds) * unsigned(W) + (size_t(xl) << ds);
+    T acc = T(0);
+#pragma unroll
+    for (int k = 0; k < 2 * kMaxPairs; ++k) {
+      if (scale[k] != T(0)) {
+        T sum = T(0);
+        for (unsigned dy = 0; dy < side; ++dy)
+          for (unsigned dx = 0; dx < side; ++dx) sum += src[k][base + (size_t)dy * unsigned(W) + dx];
+        acc += scale[k] * sum;
+      }
+    }
     dst[i] = store ? acc : dst[i] + acc;
   }
 }
@@ -918,10 +960,14 @@ static PairArgs<T> make_pair_args(const scsfm_pair_desc& d, int B, int H, int W,
                                     : (T*)nullptr);
   a.g_ref_depth = (T*)d.g_ref_depth;
   a.g_pose = (T*)d.g_pose;
+  a.ds = d.depth_shift;
   return a;
 }
 
-static bool desc_inputs_ok(const scsfm_pair_desc& d) {
+// depth_shift: the depth maps are [B, 1, H >> s, W >> s]; H and W must be multiples of 2^s
+static bool desc_inputs_ok(const scsfm_pair_desc& d, int H, int W) {
+  const int s = d.depth_shift;
+  if (s < 0 || s > 8 || ((H >> s) << s) != H || ((W >> s) << s) != W) return false;
   return d.tgt_img && d.ref_img && d.tgt_depth && d.ref_depth && d.pose && d.ws;
 }
 
@@ -953,6 +999,9 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
   PairBatch<T> pb;
   for (int i = 0; i < n; ++i) pb.p[i] = make_pair_args<T>(d[i], B, H, W, nullptr, i);
   const bool kernel_only = (flags & SCSFM_DEBUG_KERNEL_ONLY) != 0;  // profiling: consts are in place already
+  // a launch with a coarser scale's maps in it runs the kernels instantiated for the index map (DepthMap)
+  bool full_res = true;
+  for (int i = 0; i < n; ++i) full_res = full_res && d[i].depth_shift == 0;
   dim3 grid;
   if (spec) {
     const size_t npx = (size_t)B * H * W;
@@ -961,7 +1010,7 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
     const T r_hint = T(3.0 * w_geom / w_photo);
     const bool timed = g_profile.used < g_profile.n;
     if (timed) (void)hipEventRecord(g_profile.start[g_profile.used], stream);
-    if (spec_uses_strips()) {
+    if (spec_uses_strips() && full_res) {  // (the register pipeline reads full-resolution depth maps only)
       // one wave per (pair, batch element, 32-row segment, 60-column strip); kStripWaves of them per workgroup
       const int nbx = strip_nbx(W), rs = strip_rows(H, nbx * n * B, strip_slots()), nby = ceil_div(H, rs);
       const int nunits = nbx * nby * n * B;
@@ -975,7 +1024,13 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
                            flags & ~SCSFM_DEBUG_KERNEL_ONLY, r_hint);
     } else {
       grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
-      if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags)
+      if (!full_res && (flags & SCSFM_WITH_SSIM))
+        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true, kRuntimeFlags, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W,
+                           flags, r_hint);
+      else if (!full_res)
+        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, false, kRuntimeFlags, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W,
+                           flags, r_hint);
+      else if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags)
         hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true, kTrainFlags>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags,
                            r_hint);
       else if (flags & SCSFM_WITH_SSIM)
@@ -987,10 +1042,13 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
   } else {
     hipLaunchKernelGGL((pairs_prep_kernel<T>), dim3(ceil_div(n * B, 64)), dim3(64), 0, stream, pb, n, B, K);
     grid = dim3(ceil_div(W, kTileW), ceil_div(H, Tile<T>::kH), n * B);
-    if (flags & SCSFM_WITH_SSIM)
-      hipLaunchKernelGGL((pair_fwd_kernel<T, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags);
-    else
-      hipLaunchKernelGGL((pair_fwd_kernel<T, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags);
+    if (flags & SCSFM_WITH_SSIM) {
+      if (full_res) hipLaunchKernelGGL((pair_fwd_kernel<T, true, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags);
+      else hipLaunchKernelGGL((pair_fwd_kernel<T, true, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags);
+    } else {
+      if (full_res) hipLaunchKernelGGL((pair_fwd_kernel<T, false, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags);
+      else hipLaunchKernelGGL((pair_fwd_kernel<T, false, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags);
+    }
   }
   if (!kernel_only)
     hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(n), dim3(kThreads), 0, stream, pb, (int)(grid.x * grid.y * B),
@@ -1004,7 +1062,7 @@ static int pairs_fwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
   clear_status();
   if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !K) return SCSFM_ERR_ARG;
   for (int i = 0; i < n; ++i)
-    if (!desc_inputs_ok(d[i]) || !d[i].out) return SCSFM_ERR_ARG;
+    if (!desc_inputs_ok(d[i], H, W) || !d[i].out) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   // maximal runs of descriptors with the same mode (speculative or plain), at most kMaxPairs each
   int i = 0;
@@ -1025,7 +1083,7 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
   clear_status();
   if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !K || !g_photo || !g_geom) return SCSFM_ERR_ARG;
   for (int i = 0; i < n; ++i)
-    if (!desc_inputs_ok(d[i]) || !d[i].g_tgt_depth || !d[i].g_ref_depth || !d[i].g_pose || (!d[i].gbuf && !scratch))
+    if (!desc_inputs_ok(d[i], H, W) || !d[i].g_tgt_depth || !d[i].g_ref_depth || !d[i].g_pose || (!d[i].gbuf && !scratch))
       return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const size_t npx = (size_t)B * H * W;
@@ -1037,22 +1095,33 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
   for (int i0 = 0; i0 < n; i0 += kMaxPairs) {
     const int m = n - i0 < kMaxPairs ? n - i0 : kMaxPairs;
     PairBatch<T> pb;
-    for (int i = 0; i < m; ++i) pb.p[i] = make_pair_args<T>(d[i0 + i], B, H, W, scratch, i0 + i);
+    bool full_res = true;
+    for (int i = 0; i < m; ++i) {
+      pb.p[i] = make_pair_args<T>(d[i0 + i], B, H, W, scratch, i0 + i);
+      full_res = full_res && d[i0 + i].depth_shift == 0;
+    }
     const int nax = ceil_div(W, kTileW - 2), nay = ceil_div(H, Tile<T>::kH - 2);
     const int nbx = ceil_div(W, kWave), nby = ceil_div(H, kGeomRows * (kThreads / kWave));
     if (!(flags & SCSFM_DEBUG_SKIP_PHOTO)) {
       const int g = nax * nay * m * B < kPersistentGrid ? nax * nay * m * B : kPersistentGrid;
-      if (flags & SCSFM_WITH_SSIM)
-        hipLaunchKernelGGL((pair_bwd_photo_kernel<T, true>), dim3(g), dim3(kThreads), 0, stream, pb, nax, nay, m * B, B, H, W,
-                           flags, g_photo, g_geom);
-      else
-        hipLaunchKernelGGL((pair_bwd_photo_kernel<T, false>), dim3(g), dim3(kThreads), 0, stream, pb, nax, nay, m * B, B, H,
-                           W, flags, g_photo, g_geom);
+#define SCSFM_LAUNCH_PHOTO(SSIM, SCALED)                                                                                   \
+  hipLaunchKernelGGL((pair_bwd_photo_kernel<T, SSIM, SCALED>), dim3(g), dim3(kThreads), 0, stream, pb, nax, nay, m * B, B, H, \
+                     W, flags, g_photo, g_geom)
+      if (flags & SCSFM_WITH_SSIM) {
+        if (full_res) SCSFM_LAUNCH_PHOTO(true, false); else SCSFM_LAUNCH_PHOTO(true, true);
+      } else {
+        if (full_res) SCSFM_LAUNCH_PHOTO(false, false); else SCSFM_LAUNCH_PHOTO(false, true);
+      }
+#undef SCSFM_LAUNCH_PHOTO
     }
     if (!(flags & SCSFM_DEBUG_SKIP_GEOM)) {
       const int g = nbx * nby * m * B < kPersistentGrid ? nbx * nby * m * B : kPersistentGrid;
-      hipLaunchKernelGGL((pair_bwd_geom_kernel<T>), dim3(g), dim3(kThreads), 0, stream, pb, nbx, nby, m * B, B, H, W, flags,
-                         g_photo, g_geom);
+      if (full_res)
+        hipLaunchKernelGGL((pair_bwd_geom_kernel<T, false>), dim3(g), dim3(kThreads), 0, stream, pb, nbx, nby, m * B, B, H, W,
+                           flags, g_photo, g_geom);
+      else
+        hipLaunchKernelGGL((pair_bwd_geom_kernel<T, true>), dim3(g), dim3(kThreads), 0, stream, pb, nbx, nby, m * B, B, H, W,
+                           flags, g_photo, g_geom);
     }
     if (flags & SCSFM_DEBUG_SKIP_GEOM) {
       hipLaunchKernelGGL((pairs_pose_reduce_kernel<T>), dim3(m * B), dim3(kWave), 0, stream, pb, B, nbx * nby, K, g_photo,
@@ -1069,6 +1138,7 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
           while (k < cb.nd && cb.dst[k] != dst) ++k;
           if (k == cb.nd) {
             cb.dst[k] = dst;
+            cb.ds[k] = d[i0 + i].depth_shift;
             int q = 0;
             while (q < nseen && seen[q] != dst) ++q;
             cb.store[k] = (!accumulate && q == nseen && nseen < kSeenMax) ? 1 : 0;
@@ -1087,6 +1157,9 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
       // (+ 1 row of workgroups: dL/dpose)
       hipLaunchKernelGGL((pairs_combine_kernel<T>), dim3(gx, cb.nd + 1), dim3(kThreads), 0, stream, cb, npx, pb, m, B,
                          nbx * nby, K, g_photo, g_geom);
+      if (!full_res)
+        hipLaunchKernelGGL((pairs_combine_pooled_kernel<T>), dim3(gx / 4 + 1, cb.nd), dim3(kThreads), 0, stream, cb, npx, W,
+                           g_photo, g_geom);
     }
   }
   return launch_status();
@@ -1109,6 +1182,7 @@ static scsfm_pair_desc one_desc(const T* tgt_img, const T* ref_img, const T* tgt
   d.tgt_img = tgt_img; d.ref_img = ref_img; d.tgt_depth = tgt_depth; d.ref_depth = ref_depth; d.pose = pose;
   d.ws = ws; d.out = out; d.g_tgt_depth = g_tgt; d.g_ref_depth = g_ref; d.g_pose = g_pose; d.gbuf = gbuf;
   d.total = nullptr;
+  d.depth_shift = 0;
   return d;
 }
 

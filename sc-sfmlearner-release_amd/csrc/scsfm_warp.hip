@@ -332,7 +332,7 @@ static int pose_bwd(int B, const T* vec, int mode, const T* g_mat, T* g_vec, voi
 
 extern "C" {
 
-int scsfm_abi_version(void) { return 4; }
+int scsfm_abi_version(void) { return 5; }
 
 size_t scsfm_warp_ws_bytes(int B) {
   if (B <= 0) return 0;

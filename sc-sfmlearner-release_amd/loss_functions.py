@@ -44,6 +44,27 @@ class SSIM(nn.Module):
 compute_ssim_loss = SSIM().to(device)
 
 
+def _scale_maps(tgt_depth, ref_depths, n_ref, num_scales, b, h, w):
+    """The depth maps of every scale as the kernels take them (loss_functions.py:77-82).  A coarser scale whose maps are
+    [b, 1, h >> k, w >> k] (what DispResNet emits) is passed as it is: the kernels index it through the nearest
+    up-sampling's map and sum-pool the gradient (scsfm_pair_desc::depth_shift).  Any other shape is up-sampled with
+    F.interpolate under autograd, as the reference does."""
+    def fused(s):
+        maps = [tgt_depth[s]] + [ref_depths[i][s] for i in range(n_ref)]
+        return capi.depth_shift(maps[0].shape, b, h, w) is not None and all(m.shape == maps[0].shape for m in maps)
+
+    for d in [tgt_depth[0]] + [ref_depths[i][0] for i in range(n_ref)]:  # scale 0 is never re-sampled (:77-79)
+        capi.check_sizes(d, "depth", (b, 1, h, w))
+    keep = [s == 0 or fused(s) for s in range(num_scales)]
+
+    def full_res(d, s):
+        return d if keep[s] else F.interpolate(d, (h, w), mode='nearest')
+
+    tgt_full = [full_res(tgt_depth[s], s) for s in range(num_scales)]
+    ref_full = [full_res(ref_depths[i][s], s) for i in range(n_ref) for s in range(num_scales)]
+    return tgt_full, ref_full
+
+
 def compute_photo_and_geometry_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, poses, poses_inv,
                                     max_scales, with_ssim, with_mask, with_auto_mask, padding_mode):
     """loss_functions.py:50-92 -> (photo_loss, geometry_loss), summed over refs, scales and both
@@ -55,11 +76,7 @@ def compute_photo_and_geometry_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, re
     b, _, h, w = tgt_img.size()
     flags = capi.make_flags(with_ssim, with_mask, with_auto_mask, padding_mode)
 
-    def full_res(d, s):
-        return d if s == 0 else F.interpolate(d, (h, w), mode='nearest')
-
-    tgt_full = [full_res(tgt_depth[s], s) for s in range(num_scales)]
-    ref_full = [full_res(ref_depths[i][s], s) for i in range(n_ref) for s in range(num_scales)]
+    tgt_full, ref_full = _scale_maps(tgt_depth, ref_depths, n_ref, num_scales, b, h, w)
     return ops.PhotoGeometryLoss.apply(flags, n_ref, num_scales, tgt_img, intrinsics, *ref_imgs, *tgt_full, *ref_full,
                                        *poses[:n_ref], *poses_inv[:n_ref])
 
@@ -99,11 +116,7 @@ def compute_total_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, pos
     b, _, h, w = tgt_img.size()
     flags = capi.make_flags(with_ssim, with_mask, with_auto_mask, padding_mode)
 
-    def full_res(d, s):
-        return d if s == 0 else F.interpolate(d, (h, w), mode='nearest')
-
-    tgt_full = [full_res(tgt_depth[s], s) for s in range(num_scales)]
-    ref_full = [full_res(ref_depths[i][s], s) for i in range(n_ref) for s in range(num_scales)]
+    tgt_full, ref_full = _scale_maps(tgt_depth, ref_depths, n_ref, num_scales, b, h, w)
     return ops.StepLoss.apply(flags, n_ref, num_scales, float(w_photo), float(w_smooth), float(w_geom), tgt_img, intrinsics,
                               *ref_imgs, *tgt_full, *ref_full, *poses[:n_ref], *poses_inv[:n_ref])
 

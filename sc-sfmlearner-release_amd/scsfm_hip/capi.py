@@ -280,7 +280,34 @@ import functools as _ft
 class PairDesc(_ct.Structure):
     """scsfm_pair_desc of include/scsfm_hip.h."""
     _fields_ = [(n, _ct.c_void_p) for n in ("tgt_img", "ref_img", "tgt_depth", "ref_depth", "pose", "ws", "out",
-                                            "g_tgt_depth", "g_ref_depth", "g_pose", "gbuf", "total")]
+                                            "g_tgt_depth", "g_ref_depth", "g_pose", "gbuf", "total")] + \
+               [("depth_shift", _ct.c_int)]
+
+
+def depth_shift(shape, B, H, W):
+    """s >= 0 if ``shape`` is [B, 1, H >> s, W >> s] with H and W multiples of 2^s -- a depth map the pair kernels
+    read in place, its nearest up-sampling to (H, W) (loss_functions.py:77-82) folded into their index arithmetic --
+    else None."""
+    if len(shape) != 4 or shape[0] != B or shape[1] != 1:
+        return None
+    for s in range(9):
+        if (H >> s) << s != H or (W >> s) << s != W:
+            return None
+        if shape[2] == H >> s and shape[3] == W >> s:
+            return s
+    return None
+
+
+def _pair_shift(dt, dr, B, H, W):
+    """Both depth maps of a pair-direction are full resolution or the same coarser scale."""
+    full = (B, 1, H, W)
+    if tuple(dt.shape) == full and tuple(dr.shape) == full:  # (the single-scale step: no search)
+        return 0
+    s = depth_shift(dt.shape, B, H, W)
+    if s is None or tuple(dr.shape) != tuple(dt.shape):
+        check_sizes(dt, "depth", (B, 1, H, W))
+        check_sizes(dr, "depth", (B, 1, H, W))
+    return s
 
 
 @_ft.lru_cache(maxsize=64)
@@ -304,7 +331,8 @@ def _pair_list(tgt_img, ref_imgs, tgt_depths, ref_depths, poses, poses_inv):
 def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, group=None,
                        hint=None, ws=None):
     """All pair-directions of loss_functions.py:56-90 in ONE call into the library.  ``tgt_depths[s]``
-    and ``ref_depths[i][s]`` are full-resolution maps.  Returns (photo, geom, outs [n_pairs, 8], ws)
+    and ``ref_depths[i][s]`` are full-resolution maps or, for a coarser scale, [B, 1, H >> k, W >> k] maps that the
+    kernels read through the nearest up-sampling's index map (`depth_shift`).  Returns (photo, geom, outs [n_pairs, 8], ws)
     where ``ws`` (one tensor, n_pairs slices) must reach photo_geometry_bwd untouched.
 
     ``hint`` = (w_photo, w_geom): run the speculative forward (scsfm_pair_fwd_spec) -- the backward's
@@ -323,8 +351,7 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
     check_sizes(K, "intrinsics", (B, 3, 3))
     for r in ref_imgs:
         check_sizes(r, "ref_img", (B, 3, H, W))
-    for d in list(tgt_depths) + [d for r in ref_depths for d in r]:
-        check_sizes(d, "depth", (B, 1, H, W))
+    shifts = [_pair_shift(dt, dr, B, H, W) for _, _, dt, dr, _, _, _ in pairs]
     for p in list(poses) + list(poses_inv):
         check_sizes(p, "pose", (B, 6))
     ws_bytes, scratch_bytes, _ = _sizes(lib, B, H, W)
@@ -342,6 +369,7 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
             dr.data_ptr(), po.data_ptr()
         d.ws, d.out = wp + j * stride, op + j * esz
         d.gbuf = wp + j * stride + ws_bytes if spec else None
+        d.depth_shift = shifts[j]
     lib.call(f"scsfm_pairs_fwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags,
              float(hint[0]) if spec else 0.0, float(hint[1]) if spec else 0.0, _stream(tgt_img))
     if group is not None:
@@ -372,11 +400,20 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
     ws_bytes, scratch_bytes, _ = _sizes(lib, B, H, W)
     spec = ws.numel() == n * (ws_bytes + scratch_bytes)  # the forward was speculative: gbuf follows each workspace
     stride = ws_bytes + (scratch_bytes if spec else 0)
-    # one allocation for every depth-gradient buffer (full-resolution shape); the library stores into them
-    n_maps = len(tgt_depths) * (1 + len(ref_depths))
-    g_all = torch.empty((n_maps,) + tuple(tgt_depths[0].shape), dtype=tgt_img.dtype, device=tgt_img.device)
-    g_td = [g_all[s] for s in range(len(tgt_depths))]
-    g_rd = [[g_all[len(tgt_depths) * (1 + i) + s] for s in range(len(tgt_depths))] for i in range(len(ref_depths))]
+    # one allocation for every depth-gradient buffer (each of its map's shape, 64-byte aligned); the library
+    # stores into them
+    maps = list(tgt_depths) + [d for r in ref_depths for d in r]
+    if len(tgt_depths) == 1:
+        g_maps = torch.empty((len(maps),) + tuple(maps[0].shape), dtype=tgt_img.dtype, device=tgt_img.device).unbind(0)
+    else:
+        starts, total = [], 0
+        for m in maps:
+            starts.append(total)
+            total += (m.numel() + 15) // 16 * 16
+        g_all = torch.empty(total, dtype=tgt_img.dtype, device=tgt_img.device)
+        g_maps = [g_all[o:o + m.numel()].view(m.shape) for o, m in zip(starts, maps)]
+    g_td = g_maps[:len(tgt_depths)]
+    g_rd = [g_maps[len(tgt_depths) * (1 + i):len(tgt_depths) * (2 + i)] for i in range(len(ref_depths))]
     g_pose_all = torch.empty(n, B, 6, dtype=tgt_img.dtype, device=tgt_img.device)
     # one private scratch region per pair (they run concurrently); the speculative forward already
     # placed it behind each pair's workspace
@@ -394,6 +431,7 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         d.ws = wp + j * stride
         d.gbuf = wp + j * stride + ws_bytes if spec else None
         d.g_tgt_depth, d.g_ref_depth, d.g_pose = gbuf(kt).data_ptr(), gbuf(kr).data_ptr(), gp + j * psz
+        d.depth_shift = _pair_shift(dt, dr, B, H, W)
     lib.call(f"scsfm_pairs_bwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags, _p(scratch),
              _p(g_photo), _p(g_geom), _stream(tgt_img))
     n_scales = len(tgt_depths)

@@ -25,6 +25,8 @@ EXPECTED = {
     "scsfm_ssim_fwd_f32", "scsfm_ssim_bwd_f32", "scsfm_ssim_fwd_f64", "scsfm_ssim_bwd_f64",
     "scsfm_masked_mean_ws_bytes", "scsfm_masked_mean_fwd_f32", "scsfm_masked_mean_bwd_f32",
     "scsfm_masked_mean_fwd_f64", "scsfm_masked_mean_bwd_f64", "scsfm_augment_u8_f32",
+    "scsfm_pixel2cam_fwd_f32", "scsfm_pixel2cam_bwd_f32", "scsfm_pixel2cam_fwd_f64", "scsfm_pixel2cam_bwd_f64",
+    "scsfm_cam2pixel_fwd_f32", "scsfm_cam2pixel_bwd_f32", "scsfm_cam2pixel_fwd_f64", "scsfm_cam2pixel_bwd_f64",
 }
 
 

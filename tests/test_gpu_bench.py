@@ -46,7 +46,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["variants"]) >= 3
     assert {v["threads"] for v in cb["variants"]} >= {1} and any(v["anomaly_mode"] for v in cb["variants"])
     lib = r["library"]
-    assert lib["path"].endswith("scsfm_hip/libscsfm_hip.so") and lib["abi_version"] == 4 and not lib["env_override"]
+    assert lib["path"].endswith("scsfm_hip/libscsfm_hip.so") and lib["abi_version"] == 5 and not lib["env_override"]
 
 
 def test_two_ranks_sharing_the_gpu_report_a_training_rate():

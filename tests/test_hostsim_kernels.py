@@ -146,10 +146,12 @@ def test_warp_backward_fp64(lib, pad):
     assert _rel(gd2, tdl.grad) < 1e-10 and float(gr2.abs().max()) == 0 and _rel(gp2, pol.grad) < 1e-10
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("name", ["smooth", "iid"])
-def test_total_loss_fp32_matches_reference_goldens(lib, name):
+def test_total_loss_fp32_matches_reference_goldens(lib, name, fused):
     """compute_photo_and_geometry_loss + compute_smooth_loss over 2 refs, 1 and 2 scales, through the
-    same capi pipeline the autograd node uses."""
+    same capi pipeline the autograd node uses.  ``fused``: the coarser scale's maps go to the library as they are
+    (scsfm_pair_desc::depth_shift) instead of being up-sampled with F.interpolate first."""
     d = load_inputs(name)
     gold = load_npz(f"total_{name}.npz")
     H, W = d["tgt_img"].shape[-2:]
@@ -158,7 +160,7 @@ def test_total_loss_fp32_matches_reference_goldens(lib, name):
             key = f"s{n_scales}_{ssim}{mask}{auto}_{pad}"
             td = [leaf(x) for x in d["tgt_depth"]]
             rd = [[leaf(x) for x in r] for r in d["ref_depths"]]
-            up = lambda t, s: t if s == 0 else F.interpolate(t, (H, W), mode="nearest")
+            up = lambda t, s: t if s == 0 or fused else F.interpolate(t, (H, W), mode="nearest")
             td_full = [up(td[s], s) for s in range(n_scales)]
             rd_full = [[up(r[s], s) for s in range(n_scales)] for r in rd]
             det = lambda ts: [t.detach().contiguous() for t in ts]
@@ -177,7 +179,8 @@ def test_total_loss_fp32_matches_reference_goldens(lib, name):
                                                             torch.tensor([0.5]))
             # chain through the nearest up-sampling (autograd, as loss_functions.py does) and add smooth
             for s in range(n_scales):
-                td_full[s].backward(g_td[s]) if s > 0 else None
+                assert g_td[s].shape == td_full[s].shape
+                td_full[s].backward(g_td[s]) if s > 0 else None  # (fused: td_full[s] IS the leaf)
                 for i in range(2):
                     rd_full[i][s].backward(g_rd[i][s]) if s > 0 else None
             frames = [td[0]] + [r[0] for r in rd]
@@ -373,6 +376,74 @@ def test_more_pair_directions_than_one_launch_holds(lib, hint):
             assert _rel(g_rd[i][s], rd[i][s].grad) < 1e-10
     for i in range(3):
         assert _rel(g_p[i], pp[i].grad) < 1e-10 and _rel(g_pi[i], pi[i].grad) < 1e-10
+
+
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+@pytest.mark.parametrize("hint,upstream", [((1.0, 0.5), (1.0, 0.5)), ((1.0, 0.5), (0.3, 1.1)), (None, (1.0, 0.5))])
+def test_four_scales_read_in_place_fp64(lib, hint, upstream, pad):
+    """loss_functions.py:77-82 at 4 scales: the coarser maps ([B,1,H>>s,W>>s]) go to the library as they are; the
+    kernels read them through the nearest up-sampling's index map and the combining kernel sum-pools the gradients.
+    Against the oracle (which up-samples with F.interpolate under autograd) in fp64: speculative forward with a
+    holding and a failing hint, and the plain forward + two-pass backward."""
+    B, H, W = 2, 80, 104  # multiples of 8; ragged tiles on both axes
+    d = synth.make_batch(B, H, W, n_ref=2, seed=57, depth="smooth", num_scales=4)
+    c = lambda x: x.double().contiguous()
+    ti, K = c(d["tgt_img"]), c(d["intrinsics"])
+    ris = [c(r) for r in d["ref_imgs"]]
+    tds, rds = [c(t) for t in d["tgt_depth"]], [[c(t) for t in r] for r in d["ref_depths"]]
+    assert [tuple(t.shape[-2:]) for t in tds] == [(80, 104), (40, 52), (20, 26), (10, 13)]
+    ps, pis = [c(p) for p in d["poses"]], [c(p) for p in d["poses_inv"]]
+    td, rd = [leaf(t) for t in tds], [[leaf(t) for t in r] for r in rds]
+    pp, pi = [leaf(p) for p in ps], [leaf(p) for p in pis]
+    photo_o, geom_o = O.photo_and_geometry_loss(ti, ris, K, td, rd, pp, pi, 4, 1, 1, 1, pad)
+    (upstream[0] * photo_o + upstream[1] * geom_o).backward()
+    fl = capi.make_flags(1, 1, 1, pad)
+    photo, geom, outs, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=hint)
+    assert outs.shape[0] == 16
+    assert abs(float(photo) - float(photo_o)) < 1e-11 and abs(float(geom) - float(geom_o)) < 1e-11
+    g_td, g_rd, g_p, g_pi = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws,
+                                                    torch.tensor([upstream[0]], dtype=torch.float64),
+                                                    torch.tensor([upstream[1]], dtype=torch.float64))
+    for s in range(4):
+        assert g_td[s].shape == tds[s].shape
+        assert _rel(g_td[s], td[s].grad) < 1e-10, s
+        for i in range(2):
+            assert _rel(g_rd[i][s], rd[i][s].grad) < 1e-10, (i, s)
+    for i in range(2):
+        assert _rel(g_p[i], pp[i].grad) < 1e-10 and _rel(g_pi[i], pi[i].grad) < 1e-10
+
+
+def test_coarse_maps_of_unsupported_shapes(lib, monkeypatch):
+    """A coarser scale that is not an exact power-of-two reduction is up-sampled by F.interpolate in the shim (as the
+    reference does) and still matches the oracle; maps of different scales within one pair are rejected by the
+    library wrapper with check_sizes' message."""
+    import loss_functions as LF
+    from scsfm_hip import _lib, ops
+    monkeypatch.setattr(_lib, "get", lambda: lib)
+    monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)
+    B, H, W = 2, 72, 100
+    d = synth.make_batch(B, H, W, n_ref=1, seed=58, depth="smooth", num_scales=2)
+    c = lambda x: x.double().contiguous()
+    ti, K, ris = c(d["tgt_img"]), c(d["intrinsics"]), [c(d["ref_imgs"][0])]
+    odd = lambda t: c(F.interpolate(t, (H // 3, W // 3), mode="bilinear", align_corners=False))
+    tds = [c(d["tgt_depth"][0]), odd(d["tgt_depth"][0])]
+    rds = [[c(d["ref_depths"][0][0]), odd(d["ref_depths"][0][0])]]
+    ps, pis = [c(d["poses"][0])], [c(d["poses_inv"][0])]
+    td, rd = [leaf(t) for t in tds], [[leaf(t) for t in r] for r in rds]
+    photo_o, geom_o = O.photo_and_geometry_loss(ti, ris, K, td, rd, ps, pis, 2, 1, 1, 1, "zeros")
+    (photo_o + 0.5 * geom_o).backward()
+    td2, rd2 = [leaf(t) for t in tds], [[leaf(t) for t in r] for r in rds]
+    photo, geom = LF.compute_photo_and_geometry_loss(ti, ris, K, td2, rd2, ps, pis, 2, 1, 1, 1, "zeros")
+    (photo + 0.5 * geom).backward()
+    assert abs(float(photo) - float(photo_o)) < 1e-11 and abs(float(geom) - float(geom_o)) < 1e-11
+    assert _rel(td2[1].grad, td[1].grad) < 1e-10 and _rel(rd2[0][1].grad, rd[0][1].grad) < 1e-10
+    assert capi.depth_shift((B, 1, H // 2, W // 2), B, H, W) == 1 and capi.depth_shift((B, 1, H // 4, W // 4), B, H, W) == 2
+    assert capi.depth_shift((B, 1, H // 8, W // 8), B, H, W) is None  # 100 is not a multiple of 8
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    with pytest.raises(AssertionError, match="wrong size for depth"):
+        capi.photo_geometry_fwd(lib, fl, ti, K, ris, [c(d["tgt_depth"][1])], [[c(d["ref_depths"][0][0])]], ps, pis)
+    with pytest.raises(AssertionError, match="wrong size for depth"):  # scale 0 is never re-sampled
+        LF.compute_photo_and_geometry_loss(ti, ris, K, [tds[1]], [[rds[0][1]]], ps, pis, 1, 1, 1, 1, "zeros")
 
 
 @pytest.mark.parametrize("hint,upstream", [((1.0, 0.5), (1.0, 0.5)), ((1.0, 0.5), (0.3, 1.1)), (None, (1.0, 0.5))])
