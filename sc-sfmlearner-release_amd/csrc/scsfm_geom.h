@@ -387,8 +387,16 @@ __device__ __forceinline__ void lds_add(T* p, T v) {
 // contributions are rounded to nearest, so a cell's error is at most half a unit per contribution (4.8e-7) whatever
 // the order of the additions -- the window part of the scatter is bit-reproducible.  fp64 (gradient-check builds):
 // plain fp64 cells.
+// Range: a pixel whose (unscaled) gradient reaches kFixCap does not enter the window at all -- it takes the direct
+// fp32 atomics that taps outside the window take -- so a cell wraps only if more than 2048 / kFixCap = 32 pixels of
+// ONE tile (each just below the cap; typical magnitudes are below 10) pile their taps onto the same reference pixel:
+// an areal compression of the warp that no frame-to-frame motion produces.
 constexpr float kFixScale = 1048576.0f;
 constexpr float kFixInv = 1.0f / 1048576.0f;
+constexpr float kFixCap = 64.0f;
+__device__ __forceinline__ bool win_fits(const int*, float g) { return t_abs(g) < kFixCap; }
+__device__ __forceinline__ bool win_fits(const double*, double) { return true; }
+__device__ __forceinline__ bool win_fits(const float*, float) { return true; }
 template <typename T> struct WinCell { typedef int type; };
 template <> struct WinCell<double> { typedef double type; };
 __device__ __forceinline__ void win_add(int* p, float v) { lds_add(p, (int)t_floor(v * kFixScale + 0.5f)); }
@@ -403,7 +411,7 @@ __device__ __forceinline__ void scatter_taps_window(Cell (*win)[WW], int wx0, in
                                                     T* __restrict__ gplane, const Sample<T>& s, T g) {
   if (g == T(0)) return;
   const int lx = s.xa - wx0, ly = s.ya - wy0;
-  if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < WH - 1) {
+  if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < WH - 1 && win_fits(&win[0][0], g)) {
     // unpredicated: a cell of the block that is not a tap has weight 0, and adding 0 leaves it at the 0 the flush skips
     win_add(&win[ly][lx], g * s.wp[0]);
     win_add(&win[ly][lx + 1], g * s.wp[1]);

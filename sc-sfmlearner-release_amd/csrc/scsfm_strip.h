@@ -297,7 +297,7 @@ struct StripUnit {
     if (gDp != T(0)) {
       const int lx = xa - wx0, ly = ya - wy0;
       const T v0 = gDp * w00, v1 = gDp * w01, v2 = gDp * w10, v3 = gDp * w11;
-      if (unsigned(lx) < unsigned(kSWinW - 1) && unsigned(ly) < unsigned(kSWinH - 1)) {
+      if (unsigned(lx) < unsigned(kSWinW - 1) && unsigned(ly) < unsigned(kSWinH - 1) && win_fits(win, gDp)) {
         Cell* c = win + ly * kSWinW + lx;
         win_add(c, v0); win_add(c + 1, v1); win_add(c + kSWinW, v2); win_add(c + kSWinW + 1, v3);
       } else {

@@ -49,6 +49,13 @@ def _scale_maps(tgt_depth, ref_depths, n_ref, num_scales, b, h, w):
     [b, 1, h >> k, w >> k] (what DispResNet emits) is passed as it is: the kernels index it through the nearest
     up-sampling's map and sum-pool the gradient (scsfm_pair_desc::depth_shift).  Any other shape is up-sampled with
     F.interpolate under autograd, as the reference does."""
+    if num_scales == 1:  # (the usual step)
+        maps = [tgt_depth[0]] + [ref_depths[i][0] for i in range(n_ref)]
+        for d in maps:
+            if d.shape[-1] != w or d.shape[-2] != h:  # scale 0 is never re-sampled (:77-79)
+                capi.check_sizes(d, "depth", (b, 1, h, w))
+        return maps[:1], maps[1:]
+
     def fused(s):
         maps = [tgt_depth[s]] + [ref_depths[i][s] for i in range(n_ref)]
         return capi.depth_shift(maps[0].shape, b, h, w) is not None and all(m.shape == maps[0].shape for m in maps)

@@ -300,9 +300,9 @@ def depth_shift(shape, B, H, W):
 
 def _pair_shift(dt, dr, B, H, W):
     """Both depth maps of a pair-direction are full resolution or the same coarser scale."""
-    full = (B, 1, H, W)
-    if tuple(dt.shape) == full and tuple(dr.shape) == full:  # (the single-scale step: no search)
-        return 0
+    sh = dt.shape
+    if sh == dr.shape and len(sh) == 4 and sh[3] == W and sh[2] == H and sh[0] == B and sh[1] == 1:
+        return 0  # (the single-scale step: no search)
     s = depth_shift(dt.shape, B, H, W)
     if s is None or tuple(dr.shape) != tuple(dt.shape):
         check_sizes(dt, "depth", (B, 1, H, W))

@@ -337,6 +337,37 @@ def test_fp64_four_scales_read_in_place_on_hardware(dev, hint, upstream):
         assert _rel64(g_p[i], pp[i].grad) < 1e-9 and _rel64(g_pi[i], pi[i].grad) < 1e-9
 
 
+def test_large_gradients_bypass_the_fixed_point_window(dev):
+    """Twin of tests/test_hostsim_kernels.py's test of the same name on the hardware (ds_add_u32 cells of +-2048 range:
+    unscaled per-pixel terms of ~7000 must take the direct fp32 atomics)."""
+    from oracle import scsfm_oracle as O
+    from scsfm_hip import _lib, capi, synth
+    lib = _lib.get()
+    B, H, W = 2, 72, 100
+    d = synth.make_batch(B, H, W, n_ref=1, seed=61, depth="smooth")
+    g = torch.Generator().manual_seed(3)
+    tds = [1.2e-3 * (1 + 0.05 * torch.rand(B, 1, H, W, generator=g))]
+    rds = [[1.0e-3 * (1.02 + 0.05 * torch.rand(B, 1, H, W, generator=g))]]
+    p = torch.zeros(B, 6)
+    p[:, 0], p[:, 1] = 4e-7, -3e-7
+    ti, K, ris = d["tgt_img"], d["intrinsics"], d["ref_imgs"]
+    c = lambda x: x.double()
+    lf = lambda x: x.double().clone().requires_grad_(True)
+    td64, rd64 = [lf(tds[0])], [[lf(rds[0][0])]]
+    po, go = O.photo_and_geometry_loss(c(ti), [c(ris[0])], c(K), td64, rd64, [c(p)], [c(-p)], 1, 1, 1, 0, "zeros")
+    (po + 5.0 * go).backward()
+    fl = capi.make_flags(1, 1, 0, "zeros")
+    v = lambda x: x.to(dev).contiguous()
+    a = (v(ti), v(K), [v(ris[0])], [v(tds[0])], [[v(rds[0][0])]], [v(p)], [v(-p)])
+    photo, geom, outs, ws = capi.photo_geometry_fwd(lib, fl, *a, hint=(1.0, 5.0))
+    assert abs(float(photo) - float(po)) < 1e-5 and abs(float(geom) - float(go)) < 1e-5
+    t = lambda x: torch.tensor([x], device=dev)
+    g_td, g_rd, _, _ = capi.photo_geometry_bwd(lib, fl, *a, ws, t(1.0), t(5.0))
+    assert float(rd64[0][0].grad.abs().max()) * 3 * float(outs[0, 4]) > 2048
+    assert _rel64(g_rd[0][0].double(), rd64[0][0].grad) < 1e-3
+    assert _rel64(g_td[0].double(), td64[0].grad) < 1e-3
+
+
 def test_boundary_functions(IW, dev):
     """pixel2cam / cam2pixel / cam2pixel2 / legacy inverse_warp (euler and quat) on the hardware, fp64 and fp32,
     values and gradients against the oracle (tests/_boundary_checks.py; CPU twin: tests/test_boundary_names.py)."""

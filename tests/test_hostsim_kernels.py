@@ -413,6 +413,34 @@ def test_four_scales_read_in_place_fp64(lib, hint, upstream, pad):
         assert _rel(g_p[i], pp[i].grad) < 1e-10 and _rel(g_pi[i], pi[i].grad) < 1e-10
 
 
+def test_large_gradients_bypass_the_fixed_point_window(lib):
+    """The fp32 speculative forward stages dL/dD_ref in 32-bit fixed-point LDS cells (range +-2048).  Depths just
+    above cam2pixel2's 1e-3 clamp and a geometry weight of 5 make the unscaled per-pixel term r * 2Z / (Z + D_p)^2
+    ~ 7000: such pixels must take the direct fp32 atomics instead of saturating / wrapping a cell."""
+    B, H, W = 2, 72, 100
+    d = synth.make_batch(B, H, W, n_ref=1, seed=61, depth="smooth")
+    g = torch.Generator().manual_seed(3)
+    tds = [1.2e-3 * (1 + 0.05 * torch.rand(B, 1, H, W, generator=g))]
+    rds = [[1.0e-3 * (1.02 + 0.05 * torch.rand(B, 1, H, W, generator=g))]]
+    p = torch.zeros(B, 6)
+    p[:, 0], p[:, 1] = 4e-7, -3e-7  # a fraction of a pixel at this depth: one target pixel per reference pixel, off-grid
+    ps, pis = [p], [-p]
+    ti, K, ris = d["tgt_img"], d["intrinsics"], d["ref_imgs"]
+    c = lambda x: x.double()
+    td64, rd64 = [leaf(c(tds[0]))], [[leaf(c(rds[0][0]))]]
+    po, go = O.photo_and_geometry_loss(c(ti), [c(ris[0])], c(K), td64, rd64, [c(ps[0])], [c(pis[0])], 1, 1, 1, 0, "zeros")
+    (po + 5.0 * go).backward()
+    fl = capi.make_flags(1, 1, 0, "zeros")
+    photo, geom, outs, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=(1.0, 5.0))
+    assert abs(float(photo) - float(po)) < 1e-5 and abs(float(geom) - float(go)) < 1e-5
+    g_td, g_rd, _, _ = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, torch.tensor([1.0]),
+                                               torch.tensor([5.0]))
+    # the unscaled terms (gradient / the late factor a = g_photo / (3 S_mask)) are beyond a cell's range
+    assert float(rd64[0][0].grad.abs().max()) * 3 * float(outs[0, 4]) > 2048
+    assert _rel(g_rd[0][0].double(), rd64[0][0].grad) < 1e-3
+    assert _rel(g_td[0].double(), td64[0].grad) < 1e-3
+
+
 def test_coarse_maps_of_unsupported_shapes(lib, monkeypatch):
     """A coarser scale that is not an exact power-of-two reduction is up-sampled by F.interpolate in the shim (as the
     reference does) and still matches the oracle; maps of different scales within one pair are rejected by the
