@@ -226,6 +226,11 @@ def cpu_baseline(args, budget_s):
     cores = max(1, min(avail, args.cpu_threads))
     b_ref, b_gpu = min(4, args.batch), args.batch
     variants = [(cores, b_gpu, 0), (cores, b_ref, 0), (1, b_ref, 0), (cores, b_ref, 1)]
+    # "all cores", within reason: one wider row so that the line itself shows that more threads are slower on this
+    # path (measured on the 256-core host of the GPU box, batch 12: 8 threads 471 ms, 16: 386, 32: 587, 64: 1172,
+    # 128: 3386, 256: 129 s per step)
+    if avail >= 4 * cores:
+        variants.append((min(avail, 4 * cores), b_gpu, 0))
     variants = list(dict.fromkeys(variants))
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--impl", "reference" if kind == "reference" else "oracle",
            "--variants", ",".join(f"{t}:{b}:{a}" for t, b, a in variants), "--seconds", str(budget_s),
