@@ -472,16 +472,33 @@ __device__ __forceinline__ void window_origin(const BatchConsts<T>& bc, int ax, 
 // returns dL/d tgt_depth(p).  g_dd = dL/d diff_depth(p).
 // (Measured alternatives, both slower: a software pipeline that requests pixel r + 1's taps before pixel r is
 // consumed, and finishing the whole strip's arithmetic before a separate scatter loop over compact records.)
-template <typename T, typename Cell, int WW, int WH, typename Map>
-__device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py, T d, const T (&gI)[3], T g_dd,
-                                        const T* __restrict__ ref_img, const Map& ref_depth,
-                                        unsigned plane, int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
-                                        T* __restrict__ scatter_plane, T* acc) {
-  const Sample<T> s = project_pixel(bc, px, py, d, H, W, flags);
-  TapRows<T> tc[3];
+// The per-pixel body in two stages: geom_fetch projects and issues the 8 tap loads, geom_consume does the arithmetic.
+// (A software pipeline over a thread's strip -- row k + 1's gathers in flight while row k is consumed, 143 VGPRs, no
+// spills -- was measured again in round 2: 351 us instead of 343 us per launch.  The tail is bound by the vector
+// instructions it issues next to the other resident workgroups, not by the latency of its L2-resident gathers.)
+template <typename T>
+struct GeomTaps {
+  Sample<T> s;
+  TapRows<T> tc[3], td;
+};
+template <typename T, typename Map>
+__device__ __forceinline__ GeomTaps<T> geom_fetch(const BatchConsts<T>& bc, int px, int py, T d,
+                                                  const T* __restrict__ ref_img, const Map& ref_depth, unsigned plane,
+                                                  int H, int W, unsigned flags) {
+  GeomTaps<T> f;
+  f.s = project_pixel(bc, px, py, d, H, W, flags);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) tc[c] = load_tap_rows(ref_img + c * plane, s);
-  const TapRows<T> td = ref_depth.taps(s);
+  for (int c = 0; c < 3; ++c) f.tc[c] = load_tap_rows(ref_img + c * plane, f.s);
+  f.td = ref_depth.taps(f.s);
+  return f;
+}
+template <typename T, typename Cell, int WW, int WH>
+__device__ __forceinline__ T geom_consume(const BatchConsts<T>& bc, const GeomTaps<T>& f, T d, const T (&gI)[3], T g_dd,
+                                          int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
+                                          T* __restrict__ scatter_plane, T* acc) {
+  const Sample<T>& s = f.s;
+  const TapRows<T>(&tc)[3] = f.tc;
+  const TapRows<T>& td = f.td;
   const T Dp = bilerp_rows(td, s);
   const T diff = s.Z - Dp, sum = s.Z + Dp;
   const T isum = t_rcp(sum);
@@ -503,6 +520,14 @@ __device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py
   tap_rows_grad(t, s, gix, giy);
   if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, Cell, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp);
   return pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
+}
+template <typename T, typename Cell, int WW, int WH, typename Map>
+__device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py, T d, const T (&gI)[3], T g_dd,
+                                        const T* __restrict__ ref_img, const Map& ref_depth,
+                                        unsigned plane, int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
+                                        T* __restrict__ scatter_plane, T* acc) {
+  const GeomTaps<T> f = geom_fetch(bc, px, py, d, ref_img, ref_depth, plane, H, W, flags);
+  return geom_consume<T, Cell, WW, WH>(bc, f, d, gI, g_dd, H, W, flags, win, wx0, wy0, scatter_plane, acc);
 }
 
 }  // namespace scsfm
