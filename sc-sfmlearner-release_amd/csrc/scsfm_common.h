@@ -28,14 +28,17 @@ constexpr double kMaskGate = 10000.0;    // loss_functions.py:125
 constexpr double kZMin = 1e-3;           // inverse_warp.py:211
 
 // Per batch element constants written by prep_kernel: K^-1 (inverse_warp.py:253), A|c = K @ [R|t]
-// (inverse_warp.py:258-260).  24 scalars so that consecutive elements stay 32/64-byte aligned and
-// a block can fetch its element with scalar loads (the address is workgroup-uniform).
+// (inverse_warp.py:258-260), and their product M = A K^-1: pixel2cam followed by the pose transform and the
+// intrinsics is P = depth * M (u, v, 1) + c, and M (u, v, 1) splits into a column part a thread evaluates once for
+// its strip and a row part of three FMAs per pixel.  32 scalars so that consecutive elements stay 32/64-byte
+// aligned and a block can fetch its element with scalar loads (the address is workgroup-uniform).
 template <typename T>
 struct BatchConsts {
   T Kinv[9];
   T A[9];
   T c[3];
-  T pad[3];
+  T M[9];  // A K^-1: pixel (u, v, 1) * depth -> projective coordinates of the other view, minus c
+  T pad[2];
 };
 
 // Workspace layout of one pair-direction call (scsfm_pair_ws_bytes).

@@ -92,7 +92,16 @@ __device__ __forceinline__ void prep_one(int b, const T* __restrict__ pose, cons
     for (int j = 0; j < 3; ++j) o.A[3 * r + j] = k[3 * r] * R[j] + k[3 * r + 1] * R[3 + j] + k[3 * r + 2] * R[6 + j];
     o.c[r] = k[3 * r] * p[0] + k[3 * r + 1] * p[1] + k[3 * r + 2] * p[2];
   }
-  o.pad[0] = o.pad[1] = o.pad[2] = T(0);
+  // M = A K^-1, in fp64 from the rounded A (what the kernels would multiply) and the unrounded inverse
+  const double Ki[9] = {C00 * inv, -(bb * i - c * h) * inv, (bb * f - c * e) * inv,
+                        C01 * inv, (a * i - c * g) * inv, -(a * f - c * d) * inv,
+                        C02 * inv, -(a * h - bb * g) * inv, (a * e - bb * d) * inv};
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      o.M[3 * r + j] = T(double(o.A[3 * r]) * Ki[j] + double(o.A[3 * r + 1]) * Ki[3 + j] + double(o.A[3 * r + 2]) * Ki[6 + j]);
+  o.pad[0] = o.pad[1] = T(0);
   out[b] = o;
 }
 
@@ -172,8 +181,8 @@ __device__ __forceinline__ void pose_reduce_one(int b, int nblk, double scale, c
 // ------------------------------------------------------------------------------------------
 template <typename T>
 struct Sample {
-  T rx, ry, rz;     // K^-1 (u, v, 1)
-  T X, Y, Zraw, Z;  // A cam + c ; Z = max(Zraw, 1e-3) is the "computed depth"
+  T qx, qy, qz;     // M (u, v, 1) = A K^-1 (u, v, 1): d(X, Y, Zraw) / d depth
+  T X, Y, Zraw, Z;  // depth * q + c = A cam + c ; Z = max(Zraw, 1e-3) is the "computed depth"
   T gmx, gmy;       // d ix / d xn (= W/2), zeroed by the zeros-mode overwrite or the border clip
   int xa, ya;       // first column / row of the 2 x 2 block
   unsigned offr[2]; // element offset of (ya, xa) and (ya + 1, xa) inside a plane: one 8-byte load per row fetches a pair
@@ -215,13 +224,13 @@ __device__ __forceinline__ Sample<T> project_pixel(const BatchConsts<T>& bc, int
   const bool overwrite = !border && (flags & SCSFM_LEGACY_GRID) == 0;
   Sample<T> s;
   const T uf = T(u), vf = T(v);
-  s.rx = bc.Kinv[0] * uf + bc.Kinv[1] * vf + bc.Kinv[2];
-  s.ry = bc.Kinv[3] * uf + bc.Kinv[4] * vf + bc.Kinv[5];
-  s.rz = bc.Kinv[6] * uf + bc.Kinv[7] * vf + bc.Kinv[8];
-  const T cx = s.rx * depth, cy = s.ry * depth, cz = s.rz * depth;
-  s.X = bc.A[0] * cx + bc.A[1] * cy + bc.A[2] * cz + bc.c[0];
-  s.Y = bc.A[3] * cx + bc.A[4] * cy + bc.A[5] * cz + bc.c[1];
-  s.Zraw = bc.A[6] * cx + bc.A[7] * cy + bc.A[8] * cz + bc.c[2];
+  // (column part first: the pixels of a thread's strip share u, so the inner sums are evaluated once per thread)
+  s.qx = (bc.M[0] * uf + bc.M[2]) + bc.M[1] * vf;
+  s.qy = (bc.M[3] * uf + bc.M[5]) + bc.M[4] * vf;
+  s.qz = (bc.M[6] * uf + bc.M[8]) + bc.M[7] * vf;
+  s.X = s.qx * depth + bc.c[0];
+  s.Y = s.qy * depth + bc.c[1];
+  s.Zraw = s.qz * depth + bc.c[2];
   s.Z = t_max(s.Zraw, T(kZMin));
   // xn = 2 (X/Z)/(W-1) - 1 (inverse_warp.py:217-218); the two divisions are a reciprocal of Z and a
   // per-launch constant (1-2 ulp from the reference's correctly rounded quotients)
@@ -327,8 +336,10 @@ __device__ __forceinline__ void tap_rows_grad(const TapRows<T>& r, const Sample<
 //   gix, giy : dL/d(ix, iy) (un-normalised sampling coordinates)
 //   gZ       : dL/d(computed depth) arriving directly
 // Returns dL/d depth(p); adds this pixel's contribution to acc[0..8] = dL/dA, acc[9..11] = dL/dc.
+// The partials are accumulated against the PIXEL-frame point depth * (u, v, 1); pose_partials_to_A converts a
+// block's sums to dL/dA (cam = K^-1 (u, v, 1) depth is linear in it).
 template <typename T>
-__device__ __forceinline__ T pixel_geometry_bwd(const BatchConsts<T>& bc, const Sample<T>& s, T depth,
+__device__ __forceinline__ T pixel_geometry_bwd(const BatchConsts<T>& bc, const Sample<T>& s, int u, int v, T depth,
                                                 T gix, T giy, T gZ, int H, int W, T* acc) {
   // ix = ((xn+1) W - 1)/2, xn = 2 (X/Z)/(W-1) - 1   (inverse_warp.py:217-218)
   const T gqx = gix * s.gmx * (T(2) / T(W - 1));
@@ -338,15 +349,24 @@ __device__ __forceinline__ T pixel_geometry_bwd(const BatchConsts<T>& bc, const 
   const T dY = gqy * iz;
   // Z = clamp(Zraw, min=1e-3): gradient passes where Zraw >= 1e-3 (inverse_warp.py:211)
   const T dZ = (s.Zraw >= T(kZMin)) ? (gZ - (gqx * s.X + gqy * s.Y) * iz * iz) : T(0);
-  const T cx = s.rx * depth, cy = s.ry * depth, cz = s.rz * depth;
-  acc[0] += dX * cx; acc[1] += dX * cy; acc[2] += dX * cz;
-  acc[3] += dY * cx; acc[4] += dY * cy; acc[5] += dY * cz;
-  acc[6] += dZ * cx; acc[7] += dZ * cy; acc[8] += dZ * cz;
+  const T pu = T(u) * depth, pv = T(v) * depth;
+  acc[0] += dX * pu; acc[1] += dX * pv; acc[2] += dX * depth;
+  acc[3] += dY * pu; acc[4] += dY * pv; acc[5] += dY * depth;
+  acc[6] += dZ * pu; acc[7] += dZ * pv; acc[8] += dZ * depth;
   acc[9] += dX; acc[10] += dY; acc[11] += dZ;
-  const T gcx = bc.A[0] * dX + bc.A[3] * dY + bc.A[6] * dZ;
-  const T gcy = bc.A[1] * dX + bc.A[4] * dY + bc.A[7] * dZ;
-  const T gcz = bc.A[2] * dX + bc.A[5] * dY + bc.A[8] * dZ;
-  return s.rx * gcx + s.ry * gcy + s.rz * gcz;
+  return s.qx * dX + s.qy * dY + s.qz * dZ;  // (X, Y, Zraw) = depth * q + c
+}
+// dL/dA[i][j] = sum_k G[i][k] K^-1[j][k] for G = the sums of pixel_geometry_bwd's acc[0..8]; acc[9..11] = dL/dc stay.
+template <typename T, typename A>
+__device__ __forceinline__ void pose_partials_to_A(const BatchConsts<T>& bc, A* acc) {
+  A g[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      g[3 * i + j] = acc[3 * i] * A(bc.Kinv[3 * j]) + acc[3 * i + 1] * A(bc.Kinv[3 * j + 1]) + acc[3 * i + 2] * A(bc.Kinv[3 * j + 2]);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) acc[i] = g[i];
 }
 
 // Scatter dL/d(projected depth) of one pixel into the gradient of the sampled depth map
@@ -493,7 +513,7 @@ __device__ __forceinline__ GeomTaps<T> geom_fetch(const BatchConsts<T>& bc, int 
   return f;
 }
 template <typename T, typename Cell, int WW, int WH>
-__device__ __forceinline__ T geom_consume(const BatchConsts<T>& bc, const GeomTaps<T>& f, T d, const T (&gI)[3], T g_dd,
+__device__ __forceinline__ T geom_consume(const BatchConsts<T>& bc, const GeomTaps<T>& f, int px, int py, T d, const T (&gI)[3], T g_dd,
                                           int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
                                           T* __restrict__ scatter_plane, T* acc) {
   const Sample<T>& s = f.s;
@@ -519,7 +539,7 @@ __device__ __forceinline__ T geom_consume(const BatchConsts<T>& bc, const GeomTa
   T gix, giy;
   tap_rows_grad(t, s, gix, giy);
   if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, Cell, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp);
-  return pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
+  return pixel_geometry_bwd(bc, s, px, py, d, gix, giy, gZ, H, W, acc);
 }
 template <typename T, typename Cell, int WW, int WH, typename Map>
 __device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py, T d, const T (&gI)[3], T g_dd,
@@ -527,7 +547,7 @@ __device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py
                                         unsigned plane, int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
                                         T* __restrict__ scatter_plane, T* acc) {
   const GeomTaps<T> f = geom_fetch(bc, px, py, d, ref_img, ref_depth, plane, H, W, flags);
-  return geom_consume<T, Cell, WW, WH>(bc, f, d, gI, g_dd, H, W, flags, win, wx0, wy0, scatter_plane, acc);
+  return geom_consume<T, Cell, WW, WH>(bc, f, px, py, d, gI, g_dd, H, W, flags, win, wx0, wy0, scatter_plane, acc);
 }
 
 }  // namespace scsfm

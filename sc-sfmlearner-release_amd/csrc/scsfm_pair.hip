@@ -590,8 +590,12 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
     block_sum<12>(acc, red + 3 * (kThreads / kWave));  // (its barrier also orders the scatter's LDS atomics before the flush)
     if (threadIdx.x == 0) {
       double* o = pa.gPp + 12 * ((size_t)(b * nby + blk.y) * nbx + blk.x);
+      double g[12];
 #pragma unroll
-      for (int i = 0; i < 12; ++i) o[i] = double(acc[i]);
+      for (int i = 0; i < 12; ++i) g[i] = double(acc[i]);
+      pose_partials_to_A(bc, g);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) o[i] = g[i];
     }
 #pragma unroll
     for (int k = 0; k < STRIP; ++k) {
@@ -711,8 +715,12 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
   block_sum<12>(acc, red);
   if (threadIdx.x == 0) {
     double* o = gP + 12 * ((size_t)(b * nby + blk.y) * nbx + blk.x);
+    double g[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) o[i] = double(acc[i]);
+    for (int i = 0; i < 12; ++i) g[i] = double(acc[i]);
+    pose_partials_to_A(bc, g);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) o[i] = g[i];
   }
 }
 

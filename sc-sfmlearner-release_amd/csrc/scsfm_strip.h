@@ -391,13 +391,9 @@ __device__ __forceinline__ void strip_unit(const PairArgs<T>& pa, int b, int seg
   s.own_x = s.lane >= 2 && s.lane <= kWave - 3 && s.px < W;
   s.uf = T(s.u);
   {
-    // M = A K^-1 (wave-uniform; evaluated once per unit): X = (M (u, v, 1)) d + c
+    // M = A K^-1 (BatchConsts): X = (M (u, v, 1)) d + c
     const BatchConsts<T>& bc = pa.consts[b];
-    T M[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) M[3 * i + j] = bc.A[3 * i] * bc.Kinv[j] + bc.A[3 * i + 1] * bc.Kinv[3 + j] + bc.A[3 * i + 2] * bc.Kinv[6 + j];
+    const T* __restrict__ M = bc.M;
     s.qcx = M[0] * s.uf + M[2]; s.qcy = M[3] * s.uf + M[5]; s.qcz = M[6] * s.uf + M[8];
     s.qvx = M[1]; s.qvy = M[4]; s.qvz = M[7];
     s.c0 = bc.c[0]; s.c1 = bc.c[1]; s.c2 = bc.c[2];

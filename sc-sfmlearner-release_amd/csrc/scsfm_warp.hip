@@ -62,12 +62,16 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(
       scatter_taps(g_ref_depth + b * plane, s, g);
     }
     const T gZ = g_cdepth ? g_cdepth[b * plane + p] : T(0);
-    g_depth[b * plane + p] += pixel_geometry_bwd(bc, s, d, gix, giy, gZ, H, W, acc);
+    g_depth[b * plane + p] += pixel_geometry_bwd(bc, s, u, v, d, gix, giy, gZ, H, W, acc);
   }
   block_sum<12>(acc, red);
   if (threadIdx.x == 0) {
+    double g[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) atomicAdd(gP + 12 * b + i, double(acc[i]));
+    for (int i = 0; i < 12; ++i) g[i] = double(acc[i]);
+    pose_partials_to_A(bc, g);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) atomicAdd(gP + 12 * b + i, g[i]);
   }
 }
 
