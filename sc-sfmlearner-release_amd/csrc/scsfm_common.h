@@ -201,6 +201,16 @@ __device__ __forceinline__ void t_sincos(double x, double* s, double* c) { *s = 
 // Load at a 32-bit byte offset from a wave-uniform base: compiles to the scalar-base addressing mode
 // (global_load ... v_off, s[base:base+1]) with no 64-bit vector address arithmetic.  Every plane this
 // library indexes that way is far below 4 GiB (checked on the host side).
+// A read that must stay an LDS access: behind an if / else whose other side reads global memory the optimiser would
+// otherwise select between the two pointers and issue ONE flat load (through the texture path) for both.
+template <typename T>
+__device__ __forceinline__ T lds_ld(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *(const __attribute__((address_space(3))) T*)p;
+#else
+  return *p;
+#endif
+}
 template <typename T>
 __device__ __forceinline__ T ld_at(const T* __restrict__ base, unsigned byte_off) {
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);

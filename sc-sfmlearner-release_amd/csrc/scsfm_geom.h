@@ -277,6 +277,10 @@ struct TapRows { TapPair<T> n, s; };
 template <typename T>
 __device__ __forceinline__ TapRows<T> load_tap_rows(const T* __restrict__ plane, const Sample<T>& s) {
   TapRows<T> r;
+#ifdef SCSFM_EXPERIMENT_NO_GATHER  // timing experiment only (results are wrong): what do the gathers cost?
+  r.n.a = r.n.b = r.s.a = r.s.b = T(s.offr[0] & 7u) * T(0.125);
+  return r;
+#endif
   r.n = ld_at(reinterpret_cast<const TapPair<T>*>(plane), s.offr[0] * unsigned(sizeof(T)));
   r.s = ld_at(reinterpret_cast<const TapPair<T>*>(plane), s.offr[1] * unsigned(sizeof(T)));
   return r;
@@ -512,6 +516,43 @@ __device__ __forceinline__ GeomTaps<T> geom_fetch(const BatchConsts<T>& bc, int 
   f.td = ref_depth.taps(f.s);
   return f;
 }
+// The reference view's texels a tile's tail samples, staged in LDS: four planes (three colours, depth) of a
+// kStageW x kStageH window at (x0, y0), filled with coalesced row loads.  A 2 x 2 block inside it is read from LDS
+// (two 2-dword reads per plane); any other block is gathered from global memory as before.  On gfx950 a per-lane
+// gather instruction costs ~16 cycles of the CU's texture addresser whatever its width (tools/ubench/gathers.hip:
+// 59 ns per wave for the 8 gathers of one sample), a coalesced dword row 4, an LDS read 4.
+constexpr int kStageW = 72, kStageH = kTileH + 2;
+template <typename T>
+struct StagedTaps {
+  const T* colour;  // LDS: plane c of the colours starts at colour + c * stride
+  const T* depth;   // LDS
+  int stride;
+  int x0, y0;
+};
+template <typename T, typename Map>
+__device__ __forceinline__ GeomTaps<T> geom_fetch(const BatchConsts<T>& bc, int px, int py, T d,
+                                                  const T* __restrict__ ref_img, const Map& ref_depth, unsigned plane,
+                                                  int H, int W, unsigned flags, const StagedTaps<T>& st) {
+  GeomTaps<T> f;
+  f.s = project_pixel(bc, px, py, d, H, W, flags);
+  const int lx = f.s.xa - st.x0, ly = f.s.ya - st.y0;
+  if (unsigned(lx) <= unsigned(kStageW - 2) && unsigned(ly) <= unsigned(kStageH - 2)) {
+    const int o = ly * kStageW + lx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const T* p = st.colour + c * st.stride + o;
+      f.tc[c].n.a = lds_ld(p); f.tc[c].n.b = lds_ld(p + 1); f.tc[c].s.a = lds_ld(p + kStageW); f.tc[c].s.b = lds_ld(p + kStageW + 1);
+    }
+    const T* q = st.depth + o;
+    f.td.n.a = lds_ld(q); f.td.n.b = lds_ld(q + 1); f.td.s.a = lds_ld(q + kStageW); f.td.s.b = lds_ld(q + kStageW + 1);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f.tc[c] = load_tap_rows(ref_img + c * plane, f.s);
+    f.td = ref_depth.taps(f.s);
+  }
+  return f;
+}
+
 template <typename T, typename Cell, int WW, int WH>
 __device__ __forceinline__ T geom_consume(const BatchConsts<T>& bc, const GeomTaps<T>& f, int px, int py, T d, const T (&gI)[3], T g_dd,
                                           int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,

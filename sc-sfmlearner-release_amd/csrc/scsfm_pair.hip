@@ -464,6 +464,37 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
     }
     __syncthreads();
   }
+  // kSpec: the window goes where the block's pixels land: around the bounding box of their north-west taps (known
+  // since the warp), centred on it when it is larger than the window (the rest falls back to global atomics)
+  int wx0 = 0, wy0 = 0, cx0 = 0, cy0 = 0, cx1 = 0, cy1 = 0;  // window origin; cells of the window the taps can reach
+  auto scatter_box = [&]() {
+    int x0 = sBox[0][0], x1 = sBox[0][1], y0 = sBox[0][2], y1 = sBox[0][3];
+#pragma unroll
+    for (int w = 1; w < kThreads / kWave; ++w) {
+      x0 = sBox[w][0] < x0 ? sBox[w][0] : x0; x1 = sBox[w][1] > x1 ? sBox[w][1] : x1;
+      y0 = sBox[w][2] < y0 ? sBox[w][2] : y0; y1 = sBox[w][3] > y1 ? sBox[w][3] : y1;
+    }
+    if (x0 > x1) { x0 = x1 = 0; y0 = y1 = 0; }  // nothing scatters
+    const int ex = x1 - x0 + 2, ey = y1 - y0 + 2;  // cells touched (each pixel reaches one past its tap)
+    wx0 = ex <= WW ? x0 - (WW - ex) / 2 : (x0 + x1 + 1) / 2 - WW / 2;
+    wy0 = ey <= WH ? y0 - (WH - ey) / 2 : (y0 + y1 + 1) / 2 - WH / 2;
+    cx0 = x0 - wx0; cx1 = x1 + 1 - wx0; cy0 = y0 - wy0; cy1 = y1 + 1 - wy0;
+  };
+  // kStage (fp32 + SSIM): the texels the geometry tail samples -- the reference view's colours and depth around
+  // where the tile lands -- are staged in LDS at the start of the tail: the colour planes behind the parked
+  // gradients in the (then dead) tiles, the depth plane in sG.  (Requesting them here, so that the round trip hides
+  // under the SSIM phases, was measured: the 24 registers held across those phases cost more than the latency.)
+  constexpr bool kStage = kSpec && kSsim && sizeof(T) == 4 && TH == kTileH;
+  constexpr int NR = (kStageH + kThreads / kWave - 1) / (kThreads / kWave), XW = kStageW - kWave;
+  constexpr int kTileFloats = int(sizeof(V2) / sizeof(T)) * (TH + 2) * kHaloW;  // one colour's tile
+  static_assert(!kStage || kTileFloats >= TH * kTileW + kStageW * kStageH, "staging space (colours)");
+  static_assert(!kStage || 3 * TH * kTileW >= kStageW * kStageH, "staging space (depth)");
+  T* const sp_colour = reinterpret_cast<T*>(&sXY[0][0][0]) + TH * kTileW;
+  T* const sp_depth = &sG[0][0][0];
+  StagedTaps<T> staged;
+  T stage_v[kStage ? 4 : 1][kStage ? NR + 1 : 1];
+  const int er = threadIdx.x / XW, ec = kWave + threadIdx.x - er * XW;  // the columns beyond 64: (row, column) of this thread
+  if constexpr (kSpec && kSsim) scatter_box();
   // ---- phases 2/3, one colour channel at a time ------------------------------------------------
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -552,21 +583,47 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
     // scatter plane and the pose partials are all scaled by a = g_photo / (3 S_m) when they are combined)
     T* __restrict__ g_dense = pa.gbuf + kPlaneDense * gplane + (size_t)b * plane;
     T* __restrict__ g_scatter = pa.gbuf + kPlaneScatter * gplane + (size_t)b * plane;
-    // the window goes where the block's pixels land: around the bounding box of their north-west taps (known
-    // since the warp), centred on it when it is larger than the window (the rest falls back to global atomics)
-    int wx0, wy0, cx0, cy0, cx1, cy1;  // window origin; cells of the window the taps can reach
-    {
-      int x0 = sBox[0][0], x1 = sBox[0][1], y0 = sBox[0][2], y1 = sBox[0][3];
-#pragma unroll
-      for (int w = 1; w < kThreads / kWave; ++w) {
-        x0 = sBox[w][0] < x0 ? sBox[w][0] : x0; x1 = sBox[w][1] > x1 ? sBox[w][1] : x1;
-        y0 = sBox[w][2] < y0 ? sBox[w][2] : y0; y1 = sBox[w][3] > y1 ? sBox[w][3] : y1;
+    if constexpr (!kSsim) scatter_box();  // (with SSIM: done after the warp phase's barrier)
+    if constexpr (kStage) {
+      // around the taps' bounding box (cells cx0..cx1 x cy0..cy1 of the scatter window), inside the image
+      const int bx = wx0 + cx0, by = wy0 + cy0, ex = cx1 - cx0 + 1, ey = cy1 - cy0 + 1;
+      int sx0 = bx - (kStageW - ex) / 2, sy0 = by - (kStageH - ey) / 2;
+      sx0 = sx0 > W - kStageW ? W - kStageW : sx0; sx0 = sx0 < 0 ? 0 : sx0;
+      sy0 = sy0 > H - kStageH ? H - kStageH : sy0; sy0 = sy0 < 0 ? 0 : sy0;
+      staged.x0 = sx0; staged.y0 = sy0;
+      staged.colour = sp_colour; staged.depth = sp_depth; staged.stride = kTileFloats;
+      // rows by wave, 64 columns by lane; the last kStageW - 64 columns by the first threads
+      const int gx = sx0 + col < W ? sx0 + col : W - 1;
+      const int egx = sx0 + ec < W ? sx0 + ec : W - 1, egy = sy0 + er < H ? sy0 + er : H - 1;
+  #pragma unroll
+      for (int i = 0; i <= NR; ++i) {
+        const int r = strip + i * (kThreads / kWave);
+        const int gy = sy0 + r < H ? sy0 + r : H - 1;
+        const int x = i < NR ? gx : egx, y = i < NR ? gy : egy;
+        const unsigned off = (unsigned(y) * unsigned(W) + unsigned(x)) * unsigned(sizeof(T));
+        const bool on = i < NR ? r < kStageH : threadIdx.x < XW * kStageH;
+  #pragma unroll
+        for (int c = 0; c < 4; ++c) stage_v[c][i] = T(0);
+        if (on) {
+  #pragma unroll
+          for (int c = 0; c < 3; ++c) stage_v[c][i] = ld_at(ref_img + c * plane, off);
+          stage_v[3][i] = ref_depth.at(x, y, off);
+        }
       }
-      if (x0 > x1) { x0 = x1 = 0; y0 = y1 = 0; }  // nothing scatters
-      const int ex = x1 - x0 + 2, ey = y1 - y0 + 2;  // cells touched (each pixel reaches one past its tap)
-      wx0 = ex <= WW ? x0 - (WW - ex) / 2 : (x0 + x1 + 1) / 2 - WW / 2;
-      wy0 = ey <= WH ? y0 - (WH - ey) / 2 : (y0 + y1 + 1) / 2 - WH / 2;
-      cx0 = x0 - wx0; cx1 = x1 + 1 - wx0; cy0 = y0 - wy0; cy1 = y1 + 1 - wy0;
+    }
+    if constexpr (kStage) {
+      // ... and go to LDS: the tiles and sG are dead by now
+#pragma unroll
+      for (int i = 0; i <= NR; ++i) {
+        const int r = i < NR ? strip + i * (kThreads / kWave) : er, cc = i < NR ? col : ec;
+        const bool on = i < NR ? r < kStageH : threadIdx.x < XW * kStageH;
+        if (on) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) sp_colour[c * kTileFloats + r * kStageW + cc] = stage_v[c][i];
+          sp_depth[r * kStageW + cc] = stage_v[3][i];
+        }
+      }
+      __syncthreads();
     }
     T acc[12], gd[STRIP];
 #pragma unroll
@@ -581,8 +638,13 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
       for (int c = 0; c < 3; ++c) {
         if constexpr (kSsim) gI[c] = reinterpret_cast<const T*>(&sXY[c][0][0])[ly * kTileW + col]; else gI[c] = gI_reg[k][c];
       }
-      gd[k] = geom_pixel<T, Cell, WW, WH>(bc, px, py, in_d[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
-                                    wy0, g_scatter, acc);
+      if constexpr (kStage) {
+        const GeomTaps<T> f = geom_fetch(bc, px, py, in_d[k], ref_img, ref_depth, plane, H, W, flags, staged);
+        gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, in_d[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc);
+      } else {
+        gd[k] = geom_pixel<T, Cell, WW, WH>(bc, px, py, in_d[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
+                                      wy0, g_scatter, acc);
+      }
     }
     // A barrier waits for every outstanding global store / atomic of the wave, so everything that writes to
     // global memory comes after the last barrier: the round trips of the dense stores and of the window's
@@ -988,6 +1050,15 @@ static bool spec_uses_strips() {
   }();
   return strips;
 }
+// Occupancy experiments: extra dynamic LDS per workgroup of the speculative forward (SCSFM_DEBUG_EXTRA_LDS=bytes; it
+// only lowers the number of workgroups a CU holds).  Read once per process; 0 in production.
+static unsigned debug_extra_lds() {
+  static const unsigned bytes = [] {
+    const char* e = getenv("SCSFM_DEBUG_EXTRA_LDS");
+    return e ? (unsigned)strtoul(e, nullptr, 10) : 0u;
+  }();
+  return bytes;
+}
 // Waves the device holds of the strip kernel (2 per SIMD): what strip_rows() balances the launch against.
 static int strip_slots() {
   static const int slots = [] {
@@ -1033,18 +1104,18 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
     } else {
       grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
       if (!full_res && (flags & SCSFM_WITH_SSIM))
-        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true, kRuntimeFlags, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W,
+        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true, kRuntimeFlags, true>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W,
                            flags, r_hint);
       else if (!full_res)
-        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, false, kRuntimeFlags, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W,
+        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, false, kRuntimeFlags, true>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W,
                            flags, r_hint);
       else if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags)
-        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true, kTrainFlags>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags,
+        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true, kTrainFlags>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W, flags,
                            r_hint);
       else if (flags & SCSFM_WITH_SSIM)
-        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags, r_hint);
+        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W, flags, r_hint);
       else
-        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, false>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags, r_hint);
+        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, false>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W, flags, r_hint);
     }
     if (timed) (void)hipEventRecord(g_profile.stop[g_profile.used++], stream);
   } else {

@@ -27,12 +27,13 @@ def main():
     ap.add_argument("--depth", default="smooth")
     ap.add_argument("--dataset", default="kitti")
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--ssim", type=int, default=1)
     a = ap.parse_args()
     from scsfm_hip import _lib, capi
     lib = _lib.get()
     dev = torch.device("cuda:0")
     x, _ = bench.make_inputs(a, 0, dev)
-    fl = capi.make_flags(1, 1, 1, "zeros")
+    fl = capi.make_flags(a.ssim, 1, 1, "zeros")
     det = lambda t: t.detach()
     tgt, K, refs = x["tgt_img"], x["K"], x["ref_imgs"]
     tds, rds = [det(x["tgt_depth"][0])], [[det(r[0])] for r in x["ref_depths"]]
