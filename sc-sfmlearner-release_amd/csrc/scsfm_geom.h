@@ -277,10 +277,6 @@ struct TapRows { TapPair<T> n, s; };
 template <typename T>
 __device__ __forceinline__ TapRows<T> load_tap_rows(const T* __restrict__ plane, const Sample<T>& s) {
   TapRows<T> r;
-#ifdef SCSFM_EXPERIMENT_NO_GATHER  // timing experiment only (results are wrong): what do the gathers cost?
-  r.n.a = r.n.b = r.s.a = r.s.b = T(s.offr[0] & 7u) * T(0.125);
-  return r;
-#endif
   r.n = ld_at(reinterpret_cast<const TapPair<T>*>(plane), s.offr[0] * unsigned(sizeof(T)));
   r.s = ld_at(reinterpret_cast<const TapPair<T>*>(plane), s.offr[1] * unsigned(sizeof(T)));
   return r;
