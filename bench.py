@@ -42,7 +42,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy rate
 W_PHOTO, W_SMOOTH, W_GEOM = 1.0, 0.1, 0.5  # train.py:45-47 defaults used by scripts/train_resnet18_depth_256.sh
-DOMINANT_KERNEL = "pair_fwd_spec_kernel<float,true,7u>"
+DOMINANT_KERNEL = "pair_fwd_spec_kernel<float,true,7u,false>"
 
 
 def log(*a):
@@ -100,9 +100,11 @@ def pmc_traffic(args, n_pairs):
     try:
         d = json.load(open(path))
         gz = n_pairs * args.batch
-        k = d.get(f"scsfm::pair_fwd_spec_kernel<float, true, 7u>|gz{gz}") or d[f"scsfm::pair_fwd_spec_kernel<float, true>|gz{gz}"]
+        # the training-flags instantiation of the speculative forward (the template list grew over the rounds)
+        keys = [n for n in d if n.startswith("scsfm::pair_fwd_spec_kernel<float, true, 7u") and n.endswith(f"|gz{gz}")]
+        k = d[keys[0]]
         return int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
-    except (KeyError, ValueError):
+    except (KeyError, ValueError, IndexError):
         return None
 
 
