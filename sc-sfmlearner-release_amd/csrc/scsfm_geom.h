@@ -525,26 +525,30 @@ struct StagedTaps {
   int stride;
   int x0, y0;
 };
-template <typename T, typename Map>
+// kRows: rows of the staged window; kDepth: the depth plane is staged too (else it is gathered).
+template <int kRows, bool kDepth, typename T, typename Map>
 __device__ __forceinline__ GeomTaps<T> geom_fetch(const BatchConsts<T>& bc, int px, int py, T d,
                                                   const T* __restrict__ ref_img, const Map& ref_depth, unsigned plane,
                                                   int H, int W, unsigned flags, const StagedTaps<T>& st) {
   GeomTaps<T> f;
   f.s = project_pixel(bc, px, py, d, H, W, flags);
   const int lx = f.s.xa - st.x0, ly = f.s.ya - st.y0;
-  if (unsigned(lx) <= unsigned(kStageW - 2) && unsigned(ly) <= unsigned(kStageH - 2)) {
+  if (!kDepth) f.td = ref_depth.taps(f.s);
+  if (unsigned(lx) <= unsigned(kStageW - 2) && unsigned(ly) <= unsigned(kRows - 2)) {
     const int o = ly * kStageW + lx;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const T* p = st.colour + c * st.stride + o;
       f.tc[c].n.a = lds_ld(p); f.tc[c].n.b = lds_ld(p + 1); f.tc[c].s.a = lds_ld(p + kStageW); f.tc[c].s.b = lds_ld(p + kStageW + 1);
     }
-    const T* q = st.depth + o;
-    f.td.n.a = lds_ld(q); f.td.n.b = lds_ld(q + 1); f.td.s.a = lds_ld(q + kStageW); f.td.s.b = lds_ld(q + kStageW + 1);
+    if (kDepth) {
+      const T* q = st.depth + o;
+      f.td.n.a = lds_ld(q); f.td.n.b = lds_ld(q + 1); f.td.s.a = lds_ld(q + kStageW); f.td.s.b = lds_ld(q + kStageW + 1);
+    }
   } else {
 #pragma unroll
     for (int c = 0; c < 3; ++c) f.tc[c] = load_tap_rows(ref_img + c * plane, f.s);
-    f.td = ref_depth.taps(f.s);
+    if (kDepth) f.td = ref_depth.taps(f.s);
   }
   return f;
 }

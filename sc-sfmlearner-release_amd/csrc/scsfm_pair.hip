@@ -330,8 +330,11 @@ __device__ __forceinline__ unsigned pairs_to_run(const PairBatch<T>& pb, int npa
   return live;
 }
 
+#ifndef SCSFM_LEAN_LDS  // tuning knob: 1 = the speculative forward in 40 KB of LDS (see kLean), 0 = 53.6 KB
+#define SCSFM_LEAN_LDS 1
+#endif
 #ifndef SCSFM_PHOTO_BLOCKS  // tuning knob (tools/build_variants.sh): workgroups per CU the tiled pass is compiled for
-#define SCSFM_PHOTO_BLOCKS 3
+#define SCSFM_PHOTO_BLOCKS 4
 #endif
 // One tile (blk = logical tile of an nbx x nby x (pairs * B) tiling).
 // kFlags: kRuntimeFlags = obey `flags_arg`; any other value = the flag word as a compile-time constant (the
@@ -360,12 +363,21 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
   constexpr int TH = Tile<T>::kH, STRIP = TH / (kThreads / kWave);
   __shared__ V2 sXY[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];
   __shared__ T sG[kSsim ? 3 : 1][kSsim ? TH : 1][kSsim ? kTileW : 1];  // 1/9 (g_mu_y, g_E[y^2], g_E[xy]), one colour
-  __shared__ double red[kSpec ? (3 + 12) * (kThreads / kWave) : 1];  // the two block sums use disjoint parts
   // kSpec: staging window of the geometry tail's scatter (its height follows the tile's)
   constexpr int WW = kWinW, WH = kWinH * TH / kTileH;
   typedef typename WinCell<T>::type Cell;
-  __shared__ Cell win[kSpec ? WH : 1][kSpec ? WW : 1];
-  if constexpr (kSpec) {  // zeroed long before its first use (several barriers lie in between)
+  // kLean (SCSFM_LEAN_LDS, fp32 + SSIM speculative forward): 40 KB of LDS instead of 53.6 KB, so that a CU holds four
+  // workgroups: the window lives in sG (dead once the SSIM phases end; zeroed at the start of the tail), the
+  // reduction scratch behind the parked gradients and the staged colours in tile 0
+  constexpr bool kLean = SCSFM_LEAN_LDS && kSpec && kSsim && sizeof(T) == 4 && TH == kTileH;
+  constexpr int kStageRows = kLean ? kStageH - 1 : kStageH;
+  static_assert(!kLean || sizeof(Cell) * WW * WH <= sizeof(T) * 3 * TH * kTileW, "window in sG");
+  __shared__ double red_own[(kSpec && !kLean) ? (3 + 12) * (kThreads / kWave) : 1];  // the two block sums use disjoint parts
+  __shared__ Cell win_own[(kSpec && !kLean) ? WH : 1][(kSpec && !kLean) ? WW : 1];
+  double* const red = kLean ? reinterpret_cast<double*>(reinterpret_cast<T*>(&sXY[0][0][0]) + TH * kTileW + kStageW * kStageRows)
+                            : &red_own[0];
+  Cell(*const win)[WW] = kLean ? reinterpret_cast<Cell(*)[WW]>(&sG[0][0][0]) : reinterpret_cast<Cell(*)[WW]>(&win_own[0][0]);
+  if constexpr (kSpec && !kLean) {  // zeroed long before its first use (several barriers lie in between)
     for (int i = threadIdx.x; i < WW * WH; i += kThreads) (&win[0][0])[i] = Cell(0);
   }
 
@@ -485,10 +497,11 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
   // gradients in the (then dead) tiles, the depth plane in sG.  (Requesting them here, so that the round trip hides
   // under the SSIM phases, was measured: the 24 registers held across those phases cost more than the latency.)
   constexpr bool kStage = kSpec && kSsim && sizeof(T) == 4 && TH == kTileH;
-  constexpr int NR = (kStageH + kThreads / kWave - 1) / (kThreads / kWave), XW = kStageW - kWave;
+  constexpr int NR = (kStageRows + kThreads / kWave - 1) / (kThreads / kWave), XW = kStageW - kWave;
   constexpr int kTileFloats = int(sizeof(V2) / sizeof(T)) * (TH + 2) * kHaloW;  // one colour's tile
-  static_assert(!kStage || kTileFloats >= TH * kTileW + kStageW * kStageH, "staging space (colours)");
-  static_assert(!kStage || 3 * TH * kTileW >= kStageW * kStageH, "staging space (depth)");
+  static_assert(!kStage || kTileFloats >= TH * kTileW + kStageW * kStageRows + (kLean ? 2 * (3 + 12) * (kThreads / kWave) : 0),
+                "staging space (colours, + the reduction scratch in lean mode)");
+  static_assert(!kStage || 3 * TH * kTileW >= kStageW * kStageRows, "staging space (depth)");
   T* const sp_colour = reinterpret_cast<T*>(&sXY[0][0][0]) + TH * kTileW;
   T* const sp_depth = &sG[0][0][0];
   StagedTaps<T> staged;
@@ -587,9 +600,9 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
     if constexpr (kStage) {
       // around the taps' bounding box (cells cx0..cx1 x cy0..cy1 of the scatter window), inside the image
       const int bx = wx0 + cx0, by = wy0 + cy0, ex = cx1 - cx0 + 1, ey = cy1 - cy0 + 1;
-      int sx0 = bx - (kStageW - ex) / 2, sy0 = by - (kStageH - ey) / 2;
+      int sx0 = bx - (kStageW - ex) / 2, sy0 = by - (kStageRows - ey) / 2;
       sx0 = sx0 > W - kStageW ? W - kStageW : sx0; sx0 = sx0 < 0 ? 0 : sx0;
-      sy0 = sy0 > H - kStageH ? H - kStageH : sy0; sy0 = sy0 < 0 ? 0 : sy0;
+      sy0 = sy0 > H - kStageRows ? H - kStageRows : sy0; sy0 = sy0 < 0 ? 0 : sy0;
       staged.x0 = sx0; staged.y0 = sy0;
       staged.colour = sp_colour; staged.depth = sp_depth; staged.stride = kTileFloats;
       // rows by wave, 64 columns by lane; the last kStageW - 64 columns by the first threads
@@ -601,26 +614,29 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
         const int gy = sy0 + r < H ? sy0 + r : H - 1;
         const int x = i < NR ? gx : egx, y = i < NR ? gy : egy;
         const unsigned off = (unsigned(y) * unsigned(W) + unsigned(x)) * unsigned(sizeof(T));
-        const bool on = i < NR ? r < kStageH : threadIdx.x < XW * kStageH;
+        const bool on = i < NR ? r < kStageRows : threadIdx.x < XW * kStageRows;
   #pragma unroll
         for (int c = 0; c < 4; ++c) stage_v[c][i] = T(0);
         if (on) {
   #pragma unroll
           for (int c = 0; c < 3; ++c) stage_v[c][i] = ld_at(ref_img + c * plane, off);
-          stage_v[3][i] = ref_depth.at(x, y, off);
+          if (!kLean) stage_v[3][i] = ref_depth.at(x, y, off);
         }
       }
+    }
+    if constexpr (kLean) {  // the window (in sG, dead since the barrier of the block sum above)
+      for (int i = threadIdx.x; i < WW * WH; i += kThreads) (&win[0][0])[i] = Cell(0);
     }
     if constexpr (kStage) {
       // ... and go to LDS: the tiles and sG are dead by now
 #pragma unroll
       for (int i = 0; i <= NR; ++i) {
         const int r = i < NR ? strip + i * (kThreads / kWave) : er, cc = i < NR ? col : ec;
-        const bool on = i < NR ? r < kStageH : threadIdx.x < XW * kStageH;
+        const bool on = i < NR ? r < kStageRows : threadIdx.x < XW * kStageRows;
         if (on) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) sp_colour[c * kTileFloats + r * kStageW + cc] = stage_v[c][i];
-          sp_depth[r * kStageW + cc] = stage_v[3][i];
+          if (!kLean) sp_depth[r * kStageW + cc] = stage_v[3][i];
         }
       }
       __syncthreads();
@@ -639,7 +655,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
         if constexpr (kSsim) gI[c] = reinterpret_cast<const T*>(&sXY[c][0][0])[ly * kTileW + col]; else gI[c] = gI_reg[k][c];
       }
       if constexpr (kStage) {
-        const GeomTaps<T> f = geom_fetch(bc, px, py, in_d[k], ref_img, ref_depth, plane, H, W, flags, staged);
+        const GeomTaps<T> f = geom_fetch<kStageRows, !kLean>(bc, px, py, in_d[k], ref_img, ref_depth, plane, H, W, flags, staged);
         gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, in_d[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc);
       } else {
         gd[k] = geom_pixel<T, Cell, WW, WH>(bc, px, py, in_d[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
