@@ -624,6 +624,16 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
         }
       }
     }
+    T d_own[STRIP];  // depth of the owned pixels: kept since phase 0, or (kLean: 4 registers less across the SSIM phases) re-read
+#pragma unroll
+    for (int k = 0; k < STRIP; ++k) {
+      if constexpr (kLean) {
+        const int cy = py0 + k < H ? (py0 + k < 0 ? 0 : py0 + k) : H - 1, cx = px < W ? (px < 0 ? 0 : px) : W - 1;
+        d_own[k] = tgt_depth.at(cx, cy, (unsigned(cy) * unsigned(W) + unsigned(cx)) * unsigned(sizeof(T)));
+      } else {
+        d_own[k] = in_d[k];
+      }
+    }
     if constexpr (kLean) {  // the window (in sG, dead since the barrier of the block sum above)
       for (int i = threadIdx.x; i < WW * WH; i += kThreads) (&win[0][0])[i] = Cell(0);
     }
@@ -655,10 +665,10 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
         if constexpr (kSsim) gI[c] = reinterpret_cast<const T*>(&sXY[c][0][0])[ly * kTileW + col]; else gI[c] = gI_reg[k][c];
       }
       if constexpr (kStage) {
-        const GeomTaps<T> f = geom_fetch<kStageRows, !kLean>(bc, px, py, in_d[k], ref_img, ref_depth, plane, H, W, flags, staged);
-        gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, in_d[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc);
+        const GeomTaps<T> f = geom_fetch<kStageRows, !kLean>(bc, px, py, d_own[k], ref_img, ref_depth, plane, H, W, flags, staged);
+        gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, d_own[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc);
       } else {
-        gd[k] = geom_pixel<T, Cell, WW, WH>(bc, px, py, in_d[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
+        gd[k] = geom_pixel<T, Cell, WW, WH>(bc, px, py, d_own[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
                                       wy0, g_scatter, acc);
       }
     }
