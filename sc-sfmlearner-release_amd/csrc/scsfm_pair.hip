@@ -290,9 +290,9 @@ __global__ void pair_refinalize_kernel(double* __restrict__ sums, T* __restrict_
 // planes for the 62 x (TH-2) interior: gbuf[c] = dL/dI_w,c (c = 0..2), gbuf[3] = dL/d diff_depth, which
 // pass B consumes.  (History: a first fused A+B kernel needed 256 VGPRs -- 1 wave per SIMD -- because it
 // carried the sampling state of its pixels across the SSIM phases; the speculative forward below fuses
-// them again by carrying only the depth and re-projecting in the tail.  The tile code is bounded to
-// 3 waves per SIMD: at 4 it spills 52 B per lane, and that scratch traffic doubled its WRITE_SIZE and
-// cost 9 % -- profiles/r01c.)
+// them again by carrying only the depth and re-projecting in the tail.  Round 1 bounded the tile code to
+// 3 waves per SIMD -- at 4 it spilled 52 B per lane and the scratch traffic doubled its WRITE_SIZE, profiles/r01c;
+// since the end of round 2 it fits 128 VGPRs and 40 KB of LDS and runs 4 workgroups per CU: see kLean.)
 // ==========================================================================================
 //
 // kSpec = true is the SPECULATIVE FORWARD: the same tile code run as the forward pass, with unit photo
