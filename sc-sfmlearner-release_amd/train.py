@@ -170,9 +170,10 @@ def main():
 
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
-    # the reference turns the conv auto-tuner on (train.py:83); on MIOpen the first step then pays a
-    # per-layer search, which short smoke runs can switch off
-    torch.backends.cudnn.benchmark = os.environ.get("SCSFM_CUDNN_BENCHMARK", "1") != "0"
+    # the reference turns the conv auto-tuner on (train.py:83).  On MIOpen that flag means an exhaustive per-layer search
+    # -- every applicable solver compiled and timed for every convolution shape of both nets: more than 13 minutes before
+    # the first step at 256x832 -- and the step it buys is not faster (tools/e2e_probe.py), so it is off unless asked for
+    torch.backends.cudnn.benchmark = os.environ.get("SCSFM_CUDNN_BENCHMARK", "0") == "1"
 
     training_writer = _ScalarLog()
     output_writers = [_ScalarLog() for _ in range(3)] if args.log_output else []
