@@ -143,3 +143,45 @@ def test_pair_folder_follows_the_reference_layout(tmp_path):
         assert abs(float(tgt.mean()) - 40 * k) < 3 and abs(float(refs[0].mean()) - (40 * k + 10)) < 3  # (0 then 1, fixed)
         np.testing.assert_allclose(K @ Kinv, np.eye(3), atol=1e-5)
     assert seen == {0, 1, 2}
+
+
+def test_train_and_validation_loops_run_on_the_host_simulation(tmp_path, monkeypatch):
+    """train.train + train.validate_without_gt -- data loader, augmentation chain, nets, the loss path (HIP kernels via
+    tests/hostsim), optimiser, progress logging, checkpoint -- for two iterations on the synthetic data set.  The test
+    swaps the library for the simulator from OUTSIDE; the product has no such switch."""
+    import argparse
+    from hostsim import harness
+    from scsfm_hip import _lib, config as hip_config, ops
+    import train as T
+    from logger import TermLogger
+    from utils import save_checkpoint
+    lib = harness.lib()
+    monkeypatch.setattr(_lib, "get", lambda: lib)
+    monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)
+    monkeypatch.setattr(T, "device", torch.device("cpu"))
+    monkeypatch.chdir(tmp_path)
+    args = T.parser.parse_args(["synthetic:8:64x96", "--with-pretrain", "0", "-b", "2", "--epoch-size", "2", "--epochs", "1",
+                                "-j", "0", "--name", "t", "--print-freq", "1"])
+    args.save_path = str(tmp_path)
+    args.world = 1
+    for name in (args.log_summary, args.log_full):
+        open(os.path.join(args.save_path, name), "w").close()
+    torch.manual_seed(0)
+    train_set, val_set = T.build_datasets(args)
+    mk = lambda ds, shuffle: torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=shuffle, num_workers=0)
+    train_loader, val_loader = mk(train_set, True), mk(val_set, False)
+    import models
+    disp, pose = models.DispResNet(18, False), models.PoseResNet(18, False)
+    opt = torch.optim.Adam([{"params": disp.parameters()}, {"params": pose.parameters()}], lr=1e-4)
+    hip_config.set_weight_hint(args.photo_loss_weight, args.geometry_consistency_weight)
+    logger = TermLogger(n_epochs=1, train_size=2, valid_size=len(val_loader))
+    before = [p.detach().clone() for p in list(disp.parameters())[:3]]
+    loss = T.train(args, train_loader, disp, pose, opt, args.epoch_size, logger, T._ScalarLog())
+    assert loss == loss  # finite (64 x 96 x 2 pixels are below the 10000-pixel gate: the smooth term alone drives the step)
+    assert any(not torch.equal(a, b) for a, b in zip(before, list(disp.parameters())[:3]))
+    errors, names = T.validate_without_gt(args, val_loader, disp, pose, 0, logger)
+    assert len(errors) == 4 and names[0] == "Total loss" and all(e == e for e in errors)
+    rows = open(os.path.join(args.save_path, args.log_full)).read().strip().split("\n")
+    assert len(rows) == 2 and len(rows[0].split("\t")) == 4
+    save_checkpoint(args.save_path, {"epoch": 1, "state_dict": disp.state_dict()}, {"epoch": 1, "state_dict": pose.state_dict()}, True)
+    assert os.path.exists(os.path.join(args.save_path, "dispnet_model_best.pth.tar"))
