@@ -179,9 +179,15 @@ def test_train_and_validation_loops_run_on_the_host_simulation(tmp_path, monkeyp
     loss = T.train(args, train_loader, disp, pose, opt, args.epoch_size, logger, T._ScalarLog())
     assert loss == loss  # finite (64 x 96 x 2 pixels are below the 10000-pixel gate: the smooth term alone drives the step)
     assert any(not torch.equal(a, b) for a, b in zip(before, list(disp.parameters())[:3]))
+    # one more epoch with all four scales of the decoder: the coarser maps reach the kernels as they are (depth_shift)
+    args.num_scales = 4
+    logger.reset_train_bar()
+    loss4 = T.train(args, train_loader, disp, pose, opt, 1, logger, T._ScalarLog())
+    assert loss4 == loss4
+    args.num_scales = 1
     errors, names = T.validate_without_gt(args, val_loader, disp, pose, 0, logger)
     assert len(errors) == 4 and names[0] == "Total loss" and all(e == e for e in errors)
     rows = open(os.path.join(args.save_path, args.log_full)).read().strip().split("\n")
-    assert len(rows) == 2 and len(rows[0].split("\t")) == 4
+    assert len(rows) == 3 and len(rows[0].split("\t")) == 4
     save_checkpoint(args.save_path, {"epoch": 1, "state_dict": disp.state_dict()}, {"epoch": 1, "state_dict": pose.state_dict()}, True)
     assert os.path.exists(os.path.join(args.save_path, "dispnet_model_best.pth.tar"))
