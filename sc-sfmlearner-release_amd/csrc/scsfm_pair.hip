@@ -333,6 +333,9 @@ __device__ __forceinline__ unsigned pairs_to_run(const PairBatch<T>& pb, int npa
 #ifndef SCSFM_LEAN_LDS  // tuning knob: 1 = the speculative forward in 40 KB of LDS (see kLean), 0 = 53.6 KB
 #define SCSFM_LEAN_LDS 1
 #endif
+#ifndef SCSFM_STAGE_TAPS  // tuning knob: 0 = the tail gathers its taps from global memory
+#define SCSFM_STAGE_TAPS 1
+#endif
 #ifndef SCSFM_PHOTO_BLOCKS  // tuning knob (tools/build_variants.sh): workgroups per CU the tiled pass is compiled for
 #define SCSFM_PHOTO_BLOCKS 4
 #endif
@@ -496,7 +499,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
   // where the tile lands -- are staged in LDS at the start of the tail: the colour planes behind the parked
   // gradients in the (then dead) tiles, the depth plane in sG.  (Requesting them here, so that the round trip hides
   // under the SSIM phases, was measured: the 24 registers held across those phases cost more than the latency.)
-  constexpr bool kStage = kSpec && kSsim && sizeof(T) == 4 && TH == kTileH;
+  constexpr bool kStage = SCSFM_STAGE_TAPS && kSpec && kSsim && sizeof(T) == 4 && TH == kTileH;
   constexpr int NR = (kStageRows + kThreads / kWave - 1) / (kThreads / kWave), XW = kStageW - kWave;
   constexpr int kTileFloats = int(sizeof(V2) / sizeof(T)) * (TH + 2) * kHaloW;  // one colour's tile
   static_assert(!kStage || kTileFloats >= TH * kTileW + kStageW * kStageRows + (kLean ? 2 * (3 + 12) * (kThreads / kWave) : 0),
