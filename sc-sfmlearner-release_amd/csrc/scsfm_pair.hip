@@ -286,23 +286,17 @@ __global__ void pair_refinalize_kernel(double* __restrict__ sums, T* __restrict_
 //
 // Recomputes the warp inside the tile (nothing but 3 sums is kept from the forward), runs the SSIM
 // backward -- forward statistics at every pixel of the 64 x TH domain, then the transpose of
-// (reflect-pad + box) as a separable 3x3 gather -- and, as pass A of the backward proper, writes four
-// planes for the 62 x (TH-2) interior: gbuf[c] = dL/dI_w,c (c = 0..2), gbuf[3] = dL/d diff_depth, which
-// pass B consumes.  (History: a first fused A+B kernel needed 256 VGPRs -- 1 wave per SIMD -- because it
-// carried the sampling state of its pixels across the SSIM phases; the speculative forward below fuses
-// them again by carrying only the depth and re-projecting in the tail.  Round 1 bounded the tile code to
-// 3 waves per SIMD -- at 4 it spilled 52 B per lane and the scratch traffic doubled its WRITE_SIZE, profiles/r01c;
-// since the end of round 2 it fits 128 VGPRs and 40 KB of LDS and runs 4 workgroups per CU: see kLean.)
+// (reflect-pad + box) as a separable 3x3 gather -- and writes four planes for the 62 x (TH-2) interior:
+// gbuf[c] = dL/dI_w,c (c = 0..2), gbuf[3] = dL/d diff_depth, which pass B consumes.  These two passes only run
+// when the speculative forward's results do not stand (spec_valid) or no speculative forward ran.
 // ==========================================================================================
 //
-// kSpec = true is the SPECULATIVE FORWARD: the same tile code run as the forward pass, with unit photo
-// coefficient and the geometry / photo coefficient ratio r = 3 w_geom / w_photo the caller expects the
-// upstream gradients to have (the loss weights are constants of a training run, train.py:268).  It
-// produces the three sums of the forward AND carries on through pass B (the geometry tail) for the pixels
-// it owns: dL/d(warped colour) waits in LDS, the tail re-projects the pixel from the depth it kept,
-// gathers, and writes the pair's dense / scatter planes and pose partials, all up to the common factor
-// a = g_photo / (3 S_m), which is only known after the reduction and is applied when the planes are
-// combined.  If the upstream gradients turn out different (spec_valid), passes A and B run normally.
+// The SPECULATIVE FORWARD (scsfm_march.h) runs the forward with unit photo coefficient and the geometry / photo
+// coefficient ratio r = 3 w_geom / w_photo the caller expects the upstream gradients to have (the loss weights are
+// constants of a training run, train.py:268).  It produces the three sums of the forward AND carries on through
+// both passes of the backward for the pixels it owns: the pair's dense / scatter planes and pose partials, all up
+// to the common factor a = g_photo / (3 S_m), which is only known after the reduction and is applied when the
+// planes are combined.  If the upstream gradients turn out different (spec_valid), passes A and B run normally.
 template <typename T>
 __device__ __forceinline__ bool spec_valid(const double* __restrict__ sums, const T* __restrict__ g_photo,
                                            const T* __restrict__ g_geom) {
@@ -330,30 +324,30 @@ __device__ __forceinline__ unsigned pairs_to_run(const PairBatch<T>& pb, int npa
   return live;
 }
 
-#ifndef SCSFM_LEAN_LDS  // tuning knob: 1 = the speculative forward in 40 KB of LDS (see kLean), 0 = 53.6 KB
-#define SCSFM_LEAN_LDS 1
-#endif
-#ifndef SCSFM_STAGE_TAPS  // tuning knob: 0 = the tail gathers its taps from global memory
-#define SCSFM_STAGE_TAPS 1
-#endif
-#ifndef SCSFM_PHOTO_BLOCKS  // tuning knob (tools/build_variants.sh): workgroups per CU the tiled pass is compiled for
+#ifndef SCSFM_PHOTO_BLOCKS  // tuning knob (tools/build_variants.sh): workgroups per CU the tiled kernels are compiled for
 #define SCSFM_PHOTO_BLOCKS 4
 #endif
-// One tile (blk = logical tile of an nbx x nby x (pairs * B) tiling).
 // kFlags: kRuntimeFlags = obey `flags_arg`; any other value = the flag word as a compile-time constant (the
 // configuration every training run uses gets its own instantiation: its uniform branches fold away and the
 // scheduler sees longer straight-line blocks).
 constexpr unsigned kRuntimeFlags = 0xffffffffu;
 constexpr unsigned kTrainFlags = SCSFM_WITH_SSIM | SCSFM_WITH_MASK | SCSFM_WITH_AUTO_MASK;  // zeros padding
 }  // namespace scsfm
-#include "scsfm_strip.h"  // the speculative forward proper (needs PairArgs / PairBatch / the plane indices above)
+#include "scsfm_march.h"  // the speculative forward proper (needs PairArgs / PairBatch / the plane indices above)
 namespace scsfm {
 
-template <typename T, bool kSsim, bool kSpec, bool kScaled, unsigned kFlags = kRuntimeFlags>
+// The speculative forward: one (band, segment) of a (pair, batch element) per workgroup, XCD-aware order.
+template <typename T, bool kSsim, unsigned kFlags = kRuntimeFlags, bool kScaled = false>
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) void pair_fwd_spec_kernel(PairBatch<T> pb, int B, int H, int W,
+                                                                                  unsigned flags, T r_hint, int seg_rows) {
+  march_segment<T, kSsim, kScaled, kFlags>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, seg_rows, pb, B, H, W, flags, r_hint);
+}
+
+// One tile of pass A (blk = logical tile of an nbx x nby x (pairs * B) tiling).
+template <typename T, bool kSsim, bool kScaled>
 __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, const PairBatch<T>& pb, int B, int H,
-                                           int W, unsigned flags_arg, const T* __restrict__ g_photo,
-                                           const T* __restrict__ g_geom, T r_hint) {
-  const unsigned flags = kFlags == kRuntimeFlags ? flags_arg : kFlags;
+                                           int W, unsigned flags, const T* __restrict__ g_photo,
+                                           const T* __restrict__ g_geom) {
   const int pair = blk.z / B, b = blk.z - pair * B;
   const PairArgs<T>& pa = pb.p[pair];
   const T* __restrict__ tgt_img = pa.tgt_img;
@@ -361,37 +355,16 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
   const BatchConsts<T>* __restrict__ consts = pa.consts;
   const double* __restrict__ sums = pa.sums;
   T* __restrict__ gbuf = pa.gbuf;
-  double* __restrict__ partials = pa.partials;
   typedef typename Vec2<T>::type V2;
   constexpr int TH = Tile<T>::kH, STRIP = TH / (kThreads / kWave);
   __shared__ V2 sXY[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];
   __shared__ T sG[kSsim ? 3 : 1][kSsim ? TH : 1][kSsim ? kTileW : 1];  // 1/9 (g_mu_y, g_E[y^2], g_E[xy]), one colour
-  // kSpec: staging window of the geometry tail's scatter (its height follows the tile's)
-  constexpr int WW = kWinW, WH = kWinH * TH / kTileH;
-  typedef typename WinCell<T>::type Cell;
-  // kLean (SCSFM_LEAN_LDS, fp32 + SSIM speculative forward): 40 KB of LDS instead of 53.6 KB, so that a CU holds four
-  // workgroups: the window lives in sG (dead once the SSIM phases end; zeroed at the start of the tail), the
-  // reduction scratch behind the parked gradients and the staged colours in tile 0
-  constexpr bool kLean = SCSFM_LEAN_LDS && kSpec && kSsim && sizeof(T) == 4 && TH == kTileH;
-  constexpr int kStageRows = kLean ? kStageH - 1 : kStageH;
-  static_assert(!kLean || sizeof(Cell) * WW * WH <= sizeof(T) * 3 * TH * kTileW, "window in sG");
-  __shared__ double red_own[(kSpec && !kLean) ? (3 + 12) * (kThreads / kWave) : 1];  // the two block sums use disjoint parts
-  __shared__ Cell win_own[(kSpec && !kLean) ? WH : 1][(kSpec && !kLean) ? WW : 1];
-  double* const red = kLean ? reinterpret_cast<double*>(reinterpret_cast<T*>(&sXY[0][0][0]) + TH * kTileW + kStageW * kStageRows)
-                            : &red_own[0];
-  Cell(*const win)[WW] = kLean ? reinterpret_cast<Cell(*)[WW]>(&sG[0][0][0]) : reinterpret_cast<Cell(*)[WW]>(&win_own[0][0]);
-  if constexpr (kSpec && !kLean) {  // zeroed long before its first use (several barriers lie in between)
-    for (int i = threadIdx.x; i < WW * WH; i += kThreads) (&win[0][0])[i] = Cell(0);
-  }
 
   // upstream gradient x d(masked mean)/d(sum): zero when the 10000-pixel gate was closed
-  T a = T(1), bg = r_hint;
-  if constexpr (!kSpec) {
-    a = T(sums[5]) * g_photo[0];
-    bg = T(sums[6]) * g_geom[0];
-    if (a == T(0) && bg == T(0)) return;        // workgroup-uniform: pass B skips as well
-    if (spec_valid(sums, g_photo, g_geom)) return;  // the forward already left the planes in gbuf
-  }
+  const T a = T(sums[5]) * g_photo[0];
+  const T bg = T(sums[6]) * g_geom[0];
+  if (a == T(0) && bg == T(0)) return;        // workgroup-uniform: pass B skips as well
+  if (spec_valid(sums, g_photo, g_geom)) return;  // the forward already left the planes in gbuf
 
   const int col = threadIdx.x & (kWave - 1), strip = threadIdx.x / kWave;
   // the 64 x TH compute domain starts one pixel before the 62 x (TH-2) block of outputs
@@ -411,15 +384,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
   T coef[STRIP];  // a * m * (1 - dd): weight of blend_c(q) in the loss
   T mq[STRIP];    // mask of the owned pixel
   T bsum[STRIP];  // sum_c blend_c of the owned pixel
-  T acc_g = T(0), acc_m = T(0);  // kSpec: forward sums over the pixels this block owns
-  int bx0 = 1 << 30, bx1 = -(1 << 30), by0 = 1 << 30, by1 = -(1 << 30);
-  __shared__ int sBox[kSpec ? kThreads / kWave : 1][4];
   V2 cen[kSsim ? 1 : STRIP][kSsim ? 1 : 3];
-  // kSpec: dL/d(warped colour c) of the owned pixels waits for the geometry tail -- parked in the LDS tile of
-  // colour c, which is dead by the time that gradient exists (every thread only touches its own slots); in
-  // registers without SSIM
-  static_assert(!kSsim || sizeof(V2) * (TH + 2) * kHaloW >= sizeof(T) * TH * kTileW, "parking space");
-  T gI_reg[(kSpec && !kSsim) ? STRIP : 1][3];
   // ---- phase 0: every streaming load of the strip and of this thread's ring pixel ---------------
   const int u = reflect_index(px, W);
   T in_d[STRIP], in_t[STRIP][3], in_r[STRIP][3], rin_d = T(0), rin_t[3] = {T(0), T(0), T(0)}, rin_r[3];
@@ -451,23 +416,6 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
     mq[k] = inimg ? pixel_mask(s, with_auto, xy, in_r[k]) : T(0);
     coef[k] = a * mq[k] * (with_mask ? (T(1) - ddk) : T(1));
     bsum[k] = T(0);
-    if constexpr (kSpec) {
-      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) {
-        acc_g += ddk * mq[k]; acc_m += mq[k];
-        if (mq[k] != T(0)) {  // this pixel will scatter: where its north-west tap lies
-          bx0 = s.xa < bx0 ? s.xa : bx0; bx1 = s.xa > bx1 ? s.xa : bx1;
-          by0 = s.ya < by0 ? s.ya : by0; by1 = s.ya > by1 ? s.ya : by1;
-        }
-      }
-    }
-  }
-  if constexpr (kSpec) {  // bounding box of the block's scatter footprint: per wave here, met in the tail
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) {
-      const int a0 = __shfl_xor(bx0, o), a1 = __shfl_xor(bx1, o), c0 = __shfl_xor(by0, o), c1 = __shfl_xor(by1, o);
-      bx0 = a0 < bx0 ? a0 : bx0; bx1 = a1 > bx1 ? a1 : bx1; by0 = c0 < by0 ? c0 : by0; by1 = c1 > by1 ? c1 : by1;
-    }
-    if (col == 0) { sBox[strip][0] = bx0; sBox[strip][1] = bx1; sBox[strip][2] = by0; sBox[strip][3] = by1; }
   }
   // ---- phase 1b: ring ------------------------------------------------------------------------
   if constexpr (kSsim) {
@@ -479,38 +427,6 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
     }
     __syncthreads();
   }
-  // kSpec: the window goes where the block's pixels land: around the bounding box of their north-west taps (known
-  // since the warp), centred on it when it is larger than the window (the rest falls back to global atomics)
-  int wx0 = 0, wy0 = 0, cx0 = 0, cy0 = 0, cx1 = 0, cy1 = 0;  // window origin; cells of the window the taps can reach
-  auto scatter_box = [&]() {
-    int x0 = sBox[0][0], x1 = sBox[0][1], y0 = sBox[0][2], y1 = sBox[0][3];
-#pragma unroll
-    for (int w = 1; w < kThreads / kWave; ++w) {
-      x0 = sBox[w][0] < x0 ? sBox[w][0] : x0; x1 = sBox[w][1] > x1 ? sBox[w][1] : x1;
-      y0 = sBox[w][2] < y0 ? sBox[w][2] : y0; y1 = sBox[w][3] > y1 ? sBox[w][3] : y1;
-    }
-    if (x0 > x1) { x0 = x1 = 0; y0 = y1 = 0; }  // nothing scatters
-    const int ex = x1 - x0 + 2, ey = y1 - y0 + 2;  // cells touched (each pixel reaches one past its tap)
-    wx0 = ex <= WW ? x0 - (WW - ex) / 2 : (x0 + x1 + 1) / 2 - WW / 2;
-    wy0 = ey <= WH ? y0 - (WH - ey) / 2 : (y0 + y1 + 1) / 2 - WH / 2;
-    cx0 = x0 - wx0; cx1 = x1 + 1 - wx0; cy0 = y0 - wy0; cy1 = y1 + 1 - wy0;
-  };
-  // kStage (fp32 + SSIM): the texels the geometry tail samples -- the reference view's colours and depth around
-  // where the tile lands -- are staged in LDS at the start of the tail: the colour planes behind the parked
-  // gradients in the (then dead) tiles, the depth plane in sG.  (Requesting them here, so that the round trip hides
-  // under the SSIM phases, was measured: the 24 registers held across those phases cost more than the latency.)
-  constexpr bool kStage = SCSFM_STAGE_TAPS && kSpec && kSsim && sizeof(T) == 4 && TH == kTileH;
-  constexpr int NR = (kStageRows + kThreads / kWave - 1) / (kThreads / kWave), XW = kStageW - kWave;
-  constexpr int kTileFloats = int(sizeof(V2) / sizeof(T)) * (TH + 2) * kHaloW;  // one colour's tile
-  static_assert(!kStage || kTileFloats >= TH * kTileW + kStageW * kStageRows + (kLean ? 2 * (3 + 12) * (kThreads / kWave) : 0),
-                "staging space (colours, + the reduction scratch in lean mode)");
-  static_assert(!kStage || 3 * TH * kTileW >= kStageW * kStageRows, "staging space (depth)");
-  T* const sp_colour = reinterpret_cast<T*>(&sXY[0][0][0]) + TH * kTileW;
-  T* const sp_depth = &sG[0][0][0];
-  StagedTaps<T> staged;
-  T stage_v[kStage ? 4 : 1][kStage ? NR + 1 : 1];
-  const int er = threadIdx.x / XW, ec = kWave + threadIdx.x - er * XW;  // the columns beyond 64: (row, column) of this thread
-  if constexpr (kSpec && kSsim) scatter_box();
   // ---- phases 2/3, one colour channel at a time ------------------------------------------------
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -556,155 +472,22 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
     for (int k = 0; k < STRIP; ++k) {
       const int ly = strip * STRIP + k, py = py0 + k;
       // note: m(p) = 0 still receives SSIM gradient through its neighbours' windows
-      if constexpr (kSpec) {
-        if constexpr (kSsim) reinterpret_cast<T*>(&sXY[c][0][0])[ly * kTileW + col] = gI[k]; else gI_reg[k][c] = gI[k];
-      } else {
-        if (in_x && ly >= 1 && ly <= TH - 2 && py < H)
-          st_at(gbuf + (kPlaneGI + c) * gplane, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gI[k]);
-      }
+      if (in_x && ly >= 1 && ly <= TH - 2 && py < H)
+        st_at(gbuf + (kPlaneGI + c) * gplane, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gI[k]);
     }
   }
-  // dL/d diff_depth: directly (geometry loss) and through the weight mask (no detach, loss_functions.py:111-113)
-  T gdd[STRIP];
+  // dL/d diff_depth: directly (geometry loss) and through the weight mask (no detach, loss_functions.py:111-113);
+  // handed to pass B.  This tile's part of the pair's scatter plane is cleared on the way (pass B only runs when
+  // this pass did)
 #pragma unroll
-  for (int k = 0; k < STRIP; ++k) gdd[k] = bg * mq[k] - (with_mask ? a * mq[k] * bsum[k] : T(0));
-  if constexpr (!kSpec) {
-    // hand over to pass B; this tile's part of the pair's scatter plane is cleared on the way (pass B only
-    // runs when this pass did)
-#pragma unroll
-    for (int k = 0; k < STRIP; ++k) {
-      const int ly = strip * STRIP + k, py = py0 + k;
-      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) {
-        const unsigned off = (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T));
-        st_at(gbuf + kPlaneGdd * gplane, off, gdd[k]);
-        st_at(gbuf + kPlaneScatter * gplane, off, T(0));
-      }
+  for (int k = 0; k < STRIP; ++k) {
+    const int ly = strip * STRIP + k, py = py0 + k;
+    if (in_x && ly >= 1 && ly <= TH - 2 && py < H) {
+      const unsigned off = (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T));
+      st_at(gbuf + kPlaneGdd * gplane, off, bg * mq[k] - (with_mask ? a * mq[k] * bsum[k] : T(0)));
+      st_at(gbuf + kPlaneScatter * gplane, off, T(0));
     }
-  } else {
-    // ---- the forward's three sums over the pixels this block owns ---------------------------------
-    T v[3] = {T(0), acc_g, acc_m};
-#pragma unroll
-    for (int k = 0; k < STRIP; ++k) {
-      const int ly = strip * STRIP + k, py = py0 + k;
-      // with a = 1, coef = m * (1 - dd) (or m): exactly the weight of blend in the photo sum
-      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) v[0] += bsum[k] * coef[k];
-    }
-    block_sum<3>(v, red);  // (contains a barrier: the window's zeroes are visible below even without SSIM)
-    if (threadIdx.x == 0) {
-      double* o = partials + 3 * ((size_t)(b * nby + blk.y) * nbx + blk.x);
-      o[0] = double(v[0]); o[1] = double(v[1]); o[2] = double(v[2]);
-    }
-    // ---- geometry tail: pass B for the owned pixels, up to the factor the reduction will supply ----
-    // (everything downstream of dL/d(warped colour), dL/d diff_depth is linear in them: the dense plane, the
-    // scatter plane and the pose partials are all scaled by a = g_photo / (3 S_m) when they are combined)
-    T* __restrict__ g_dense = pa.gbuf + kPlaneDense * gplane + (size_t)b * plane;
-    T* __restrict__ g_scatter = pa.gbuf + kPlaneScatter * gplane + (size_t)b * plane;
-    if constexpr (!kSsim) scatter_box();  // (with SSIM: done after the warp phase's barrier)
-    if constexpr (kStage) {
-      // around the taps' bounding box (cells cx0..cx1 x cy0..cy1 of the scatter window), inside the image
-      const int bx = wx0 + cx0, by = wy0 + cy0, ex = cx1 - cx0 + 1, ey = cy1 - cy0 + 1;
-      int sx0 = bx - (kStageW - ex) / 2, sy0 = by - (kStageRows - ey) / 2;
-      sx0 = sx0 > W - kStageW ? W - kStageW : sx0; sx0 = sx0 < 0 ? 0 : sx0;
-      sy0 = sy0 > H - kStageRows ? H - kStageRows : sy0; sy0 = sy0 < 0 ? 0 : sy0;
-      staged.x0 = sx0; staged.y0 = sy0;
-      staged.colour = sp_colour; staged.depth = sp_depth; staged.stride = kTileFloats;
-      // rows by wave, 64 columns by lane; the last kStageW - 64 columns by the first threads
-      const int gx = sx0 + col < W ? sx0 + col : W - 1;
-      const int egx = sx0 + ec < W ? sx0 + ec : W - 1, egy = sy0 + er < H ? sy0 + er : H - 1;
-  #pragma unroll
-      for (int i = 0; i <= NR; ++i) {
-        const int r = strip + i * (kThreads / kWave);
-        const int gy = sy0 + r < H ? sy0 + r : H - 1;
-        const int x = i < NR ? gx : egx, y = i < NR ? gy : egy;
-        const unsigned off = (unsigned(y) * unsigned(W) + unsigned(x)) * unsigned(sizeof(T));
-        const bool on = i < NR ? r < kStageRows : threadIdx.x < XW * kStageRows;
-  #pragma unroll
-        for (int c = 0; c < 4; ++c) stage_v[c][i] = T(0);
-        if (on) {
-  #pragma unroll
-          for (int c = 0; c < 3; ++c) stage_v[c][i] = ld_at(ref_img + c * plane, off);
-          if (!kLean) stage_v[3][i] = ref_depth.at(x, y, off);
-        }
-      }
-    }
-    T d_own[STRIP];  // depth of the owned pixels: kept since phase 0, or (kLean: 4 registers less across the SSIM phases) re-read
-#pragma unroll
-    for (int k = 0; k < STRIP; ++k) {
-      if constexpr (kLean) {
-        const int cy = py0 + k < H ? (py0 + k < 0 ? 0 : py0 + k) : H - 1, cx = px < W ? (px < 0 ? 0 : px) : W - 1;
-        d_own[k] = tgt_depth.at(cx, cy, (unsigned(cy) * unsigned(W) + unsigned(cx)) * unsigned(sizeof(T)));
-      } else {
-        d_own[k] = in_d[k];
-      }
-    }
-    if constexpr (kLean) {  // the window (in sG, dead since the barrier of the block sum above)
-      for (int i = threadIdx.x; i < WW * WH; i += kThreads) (&win[0][0])[i] = Cell(0);
-    }
-    if constexpr (kStage) {
-      // ... and go to LDS: the tiles and sG are dead by now
-#pragma unroll
-      for (int i = 0; i <= NR; ++i) {
-        const int r = i < NR ? strip + i * (kThreads / kWave) : er, cc = i < NR ? col : ec;
-        const bool on = i < NR ? r < kStageRows : threadIdx.x < XW * kStageRows;
-        if (on) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) sp_colour[c * kTileFloats + r * kStageW + cc] = stage_v[c][i];
-          if (!kLean) sp_depth[r * kStageW + cc] = stage_v[3][i];
-        }
-      }
-      __syncthreads();
-    }
-    T acc[12], gd[STRIP];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = T(0);
-#pragma unroll
-    for (int k = 0; k < STRIP; ++k) {
-      const int ly = strip * STRIP + k, py = py0 + k;
-      gd[k] = T(0);
-      if (!(in_x && ly >= 1 && ly <= TH - 2 && py < H) || (flags & SCSFM_DEBUG_X4)) continue;
-      T gI[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        if constexpr (kSsim) gI[c] = reinterpret_cast<const T*>(&sXY[c][0][0])[ly * kTileW + col]; else gI[c] = gI_reg[k][c];
-      }
-      if constexpr (kStage) {
-        const GeomTaps<T> f = geom_fetch<kStageRows, !kLean>(bc, px, py, d_own[k], ref_img, ref_depth, plane, H, W, flags, staged);
-        gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, d_own[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc);
-      } else {
-        gd[k] = geom_pixel<T, Cell, WW, WH>(bc, px, py, d_own[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
-                                      wy0, g_scatter, acc);
-      }
-    }
-    // A barrier waits for every outstanding global store / atomic of the wave, so everything that writes to
-    // global memory comes after the last barrier: the round trips of the dense stores and of the window's
-    // atomics then overlap with the next workgroup instead of stalling this one.
-    block_sum<12>(acc, red + 3 * (kThreads / kWave));  // (its barrier also orders the scatter's LDS atomics before the flush)
-    if (threadIdx.x == 0) {
-      double* o = pa.gPp + 12 * ((size_t)(b * nby + blk.y) * nbx + blk.x);
-      double g[12];
-#pragma unroll
-      for (int i = 0; i < 12; ++i) g[i] = double(acc[i]);
-      pose_partials_to_A(bc, g);
-#pragma unroll
-      for (int i = 0; i < 12; ++i) o[i] = g[i];
-    }
-#pragma unroll
-    for (int k = 0; k < STRIP; ++k) {
-      const int ly = strip * STRIP + k, py = py0 + k;
-      if (in_x && ly >= 1 && ly <= TH - 2 && py < H && !(flags & SCSFM_DEBUG_X4))
-        st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gd[k]);
-    }
-    if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5)))
-      flush_scatter_region<T, Cell, WW, WH>(win, wx0, wy0, cx0, cy0, cx1, cy1, g_scatter, W);
   }
-}
-
-// The speculative forward: one tile per workgroup, XCD-aware order.
-template <typename T, bool kSsim, unsigned kFlags = kRuntimeFlags, bool kScaled = false>
-__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) void pair_fwd_spec_kernel(PairBatch<T> pb, int B, int H, int W,
-                                                                                  unsigned flags, T r_hint) {
-  photo_tile<T, kSsim, true, kScaled, kFlags>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, pb, B, H, W, flags, nullptr, nullptr,
-                                     r_hint);
 }
 
 // Pass A of the backward.  Launched with a small persistent grid that walks the tiles: when the speculative
@@ -720,7 +503,7 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) 
   for (int t = blockIdx.x; t < n; t += gridDim.x) {
     const BlockId blk = xcd_tile_of(t, nbx, nby, nz);
     if (!((live >> (blk.z / B)) & 1u)) continue;
-    photo_tile<T, kSsim, false, kScaled>(blk, nbx, nby, pb, B, H, W, flags, g_photo, g_geom, T(0));
+    photo_tile<T, kSsim, kScaled>(blk, nbx, nby, pb, B, H, W, flags, g_photo, g_geom);
     __syncthreads();  // the tile's LDS is reused
   }
 }
@@ -1070,15 +853,6 @@ static bool desc_inputs_ok(const scsfm_pair_desc& d, int H, int W) {
   return d.tgt_img && d.ref_img && d.tgt_depth && d.ref_depth && d.pose && d.ws;
 }
 
-// Which kernel serves the speculative forward: the per-wave register pipeline (scsfm_strip.h) or the LDS-tiled
-// kernel (default; SCSFM_SPEC_KERNEL=strip selects the register pipeline for A/B measurements).  Read once per process.
-static bool spec_uses_strips() {
-  static const bool strips = [] {
-    const char* e = getenv("SCSFM_SPEC_KERNEL");
-    return e && e[0] == 's';
-  }();
-  return strips;
-}
 // Occupancy experiments: extra dynamic LDS per workgroup of the speculative forward (SCSFM_DEBUG_EXTRA_LDS=bytes; it
 // only lowers the number of workgroups a CU holds).  Read once per process; 0 in production.
 static unsigned debug_extra_lds() {
@@ -1088,16 +862,21 @@ static unsigned debug_extra_lds() {
   }();
   return bytes;
 }
-// Waves the device holds of the strip kernel (2 per SIMD): what strip_rows() balances the launch against.
-static int strip_slots() {
-  static const int slots = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus <= 0)
-      cus = 256;
-    return cus * 8;
+// Rows of a segment of the speculative forward's column march (scsfm_march.h).  A segment costs 4 extra warped rows
+// and a last, mostly idle chunk, so segments should be long; the launch should still be many times the 1024
+// workgroups the chip holds (4 per CU), so they cannot be too long.  SCSFM_MARCH_ROWS overrides (tests, tuning).
+static int march_seg_rows(int H, int chunk, int units) {
+  static const int forced = [] {
+    const char* e = getenv("SCSFM_MARCH_ROWS");
+    return e ? atoi(e) : 0;
   }();
-  return slots;
+  int rows = forced > 0 ? forced : 64;
+  if (forced <= 0) {
+    // short of four rounds of workgroups: halve the segments (down to two chunks)
+    while (rows > 2 * chunk && (long)units * ceil_div(H, rows) < 4 * 1024) rows /= 2;
+  }
+  rows = ceil_div(rows, chunk) * chunk;
+  return rows < H ? rows : ceil_div(H, chunk) * chunk;
 }
 
 // Forward of up to kMaxPairs pair-directions per launch.  `spec`: every pair has a gbuf and w_photo != 0.
@@ -1118,33 +897,19 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
     const T r_hint = T(3.0 * w_geom / w_photo);
     const bool timed = g_profile.used < g_profile.n;
     if (timed) (void)hipEventRecord(g_profile.start[g_profile.used], stream);
-    if (spec_uses_strips() && full_res) {  // (the register pipeline reads full-resolution depth maps only)
-      // one wave per (pair, batch element, 32-row segment, 60-column strip); kStripWaves of them per workgroup
-      const int nbx = strip_nbx(W), rs = strip_rows(H, nbx * n * B, strip_slots()), nby = ceil_div(H, rs);
-      const int nunits = nbx * nby * n * B;
-      grid = dim3(nbx, nby, n * B);  // (what the finalize kernel sizes its reduction by: units per pair = nbx * nby * B)
-      const dim3 launch_grid(ceil_div(nunits, kStripWaves));
-      if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags)
-        hipLaunchKernelGGL((pair_strip_kernel<T, kTrainFlags>), launch_grid, dim3(kThreads), 0, stream, pb, B, H, W, nbx, nby,
-                           rs, nunits, flags, r_hint);
-      else
-        hipLaunchKernelGGL((pair_strip_kernel<T>), launch_grid, dim3(kThreads), 0, stream, pb, B, H, W, nbx, nby, rs, nunits,
-                           flags & ~SCSFM_DEBUG_KERNEL_ONLY, r_hint);
-    } else {
-      grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
-      if (!full_res && (flags & SCSFM_WITH_SSIM))
-        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true, kRuntimeFlags, true>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W,
-                           flags, r_hint);
-      else if (!full_res)
-        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, false, kRuntimeFlags, true>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W,
-                           flags, r_hint);
-      else if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags)
-        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true, kTrainFlags>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W, flags,
-                           r_hint);
-      else if (flags & SCSFM_WITH_SSIM)
-        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, true>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W, flags, r_hint);
-      else
-        hipLaunchKernelGGL((pair_fwd_spec_kernel<T, false>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W, flags, r_hint);
+    {
+      const int nbands = ceil_div(W, kBandOut);
+      const int rows = march_seg_rows(H, March<T>::kStrip * (kThreads / kWave), nbands * n * B);
+      grid = dim3(nbands, ceil_div(H, rows), n * B);
+#define SCSFM_LAUNCH_SPEC(...)                                                                                          \
+  hipLaunchKernelGGL((pair_fwd_spec_kernel<T, __VA_ARGS__>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W, \
+                     flags & ~SCSFM_DEBUG_KERNEL_ONLY, r_hint, rows)
+      if (!full_res && (flags & SCSFM_WITH_SSIM)) SCSFM_LAUNCH_SPEC(true, kRuntimeFlags, true);
+      else if (!full_res) SCSFM_LAUNCH_SPEC(false, kRuntimeFlags, true);
+      else if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags) SCSFM_LAUNCH_SPEC(true, kTrainFlags);
+      else if (flags & SCSFM_WITH_SSIM) SCSFM_LAUNCH_SPEC(true);
+      else SCSFM_LAUNCH_SPEC(false);
+#undef SCSFM_LAUNCH_SPEC
     }
     if (timed) (void)hipEventRecord(g_profile.stop[g_profile.used++], stream);
   } else {
