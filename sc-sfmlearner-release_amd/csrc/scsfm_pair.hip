@@ -866,10 +866,8 @@ static unsigned debug_extra_lds() {
 // and a last, mostly idle chunk, so segments should be long; the launch should still be many times the 1024
 // workgroups the chip holds (4 per CU), so they cannot be too long.  SCSFM_MARCH_ROWS overrides (tests, tuning).
 static int march_seg_rows(int H, int chunk, int units) {
-  static const int forced = [] {
-    const char* e = getenv("SCSFM_MARCH_ROWS");
-    return e ? atoi(e) : 0;
-  }();
+  const char* e = getenv("SCSFM_MARCH_ROWS");  // (read per launch: tools/march_sweep.py varies it inside one process)
+  const int forced = e ? atoi(e) : 0;
   int rows = forced > 0 ? forced : 64;
   if (forced <= 0) {
     // short of four rounds of workgroups: halve the segments (down to two chunks)
