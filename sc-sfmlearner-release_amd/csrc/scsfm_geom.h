@@ -456,7 +456,7 @@ __device__ __forceinline__ void flush_scatter_window(const Cell (*win)[WW], int 
 // The same flush restricted to the cells [cx0, cx1] x [cy0, cy1] of the window (inclusive, window coordinates;
 // clamped into it) that can be non-zero: the bounding box of the block's taps is usually half the window, so
 // half as many atomic instructions are issued, each with (nearly) all of its lanes active.
-template <typename T, typename Cell, int WW, int WH>
+template <typename T, typename Cell, int WW, int WH, int NT = kThreads>
 __device__ __forceinline__ void flush_scatter_region(const Cell (*win)[WW], int wx0, int wy0, int cx0,
                                                      int cy0, int cx1, int cy1, T* __restrict__ gplane, int W) {
   cx0 = cx0 < 0 ? 0 : cx0; cy0 = cy0 < 0 ? 0 : cy0;
@@ -464,7 +464,7 @@ __device__ __forceinline__ void flush_scatter_region(const Cell (*win)[WW], int 
   const int w = cx1 - cx0 + 1, h = cy1 - cy0 + 1;
   if (w <= 0 || h <= 0) return;
   const float iw = 1.0f / float(w);
-  for (int i = threadIdx.x; i < w * h; i += kThreads) {
+  for (int i = threadIdx.x; i < w * h; i += NT) {
     const int ry = int((float(i) + 0.5f) * iw);  // i / w, exact for the few thousand cells of a window
     const int ly = cy0 + ry, lx = cx0 + (i - ry * w);
     const Cell v = win[ly][lx];

@@ -336,10 +336,13 @@ constexpr unsigned kTrainFlags = SCSFM_WITH_SSIM | SCSFM_WITH_MASK | SCSFM_WITH_
 #include "scsfm_march.h"  // the speculative forward proper (needs PairArgs / PairBatch / the plane indices above)
 namespace scsfm {
 
+#ifndef SCSFM_MARCH_WAVES_PER_SIMD  // tuning knob: waves per SIMD the speculative forward is compiled for (128 VGPRs at 4)
+#define SCSFM_MARCH_WAVES_PER_SIMD 4
+#endif
 // The speculative forward: one (band, segment) of a (pair, batch element) per workgroup, XCD-aware order.
 template <typename T, bool kSsim, unsigned kFlags = kRuntimeFlags, bool kScaled = false>
-__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) void pair_fwd_spec_kernel(PairBatch<T> pb, int B, int H, int W,
-                                                                                  unsigned flags, T r_hint, int seg_rows) {
+__global__ __launch_bounds__(March<T>::kWaves * kWave, sizeof(T) == 4 ? SCSFM_MARCH_WAVES_PER_SIMD : 1) void pair_fwd_spec_kernel(
+    PairBatch<T> pb, int B, int H, int W, unsigned flags, T r_hint, int seg_rows) {
   march_segment<T, kSsim, kScaled, kFlags>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, seg_rows, pb, B, H, W, flags, r_hint);
 }
 
@@ -897,10 +900,10 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
     if (timed) (void)hipEventRecord(g_profile.start[g_profile.used], stream);
     {
       const int nbands = ceil_div(W, kBandOut);
-      const int rows = march_seg_rows(H, March<T>::kStrip * (kThreads / kWave), nbands * n * B);
+      const int rows = march_seg_rows(H, March<T>::kStrip * March<T>::kWaves, nbands * n * B);
       grid = dim3(nbands, ceil_div(H, rows), n * B);
 #define SCSFM_LAUNCH_SPEC(...)                                                                                          \
-  hipLaunchKernelGGL((pair_fwd_spec_kernel<T, __VA_ARGS__>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W, \
+  hipLaunchKernelGGL((pair_fwd_spec_kernel<T, __VA_ARGS__>), grid, dim3(March<T>::kWaves * kWave), debug_extra_lds(), stream, pb, B, H, W, \
                      flags & ~SCSFM_DEBUG_KERNEL_ONLY, r_hint, rows)
       if (!full_res && (flags & SCSFM_WITH_SSIM)) SCSFM_LAUNCH_SPEC(true, kRuntimeFlags, true);
       else if (!full_res) SCSFM_LAUNCH_SPEC(false, kRuntimeFlags, true);
@@ -1141,6 +1144,13 @@ size_t scsfm_pair_ws_bytes(int B, int H, int W) {
   int scsfm_pair_refinalize_##SUF(int B, int H, int W, void* ws, T* out, void* stream) {                              \
     return scsfm::pair_refinalize<T>(B, H, W, ws, out, stream);                                                       \
   }
+
+#ifdef PROBE_TIMING
+int scsfm_probe_read(unsigned long long* host, size_t n) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(scsfm::g_probe), n * sizeof(unsigned long long));
+}
+#endif
 
 SCSFM_PAIR_API(f32, float)
 SCSFM_PAIR_API(f64, double)
