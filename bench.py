@@ -156,7 +156,7 @@ def time_kernels(x, flags, iters, n_ref):
     return {k: _event_time(fn, iters) for k, fn in calls.items()}
 
 
-def e2e_train(args, device, world, dev_index, barrier):
+def e2e_train(args, device, world, dev_index, barrier, dist_on=False):
     """K timed whole training steps of BASELINE.json's metric (train.py:249-286): 3 DispResNet + 4 PoseResNet18
     forwards (PyTorch-ROCm / MIOpen), the HIP loss path, backward, Adam; data parallel with
     DistributedDataParallel (train.wrap_ddp) when world > 1.  Synthetic batch resident in HBM, random-init nets.
@@ -168,11 +168,14 @@ def e2e_train(args, device, world, dev_index, barrier):
     torch.manual_seed(0)
     targs = _ap.Namespace(photo_loss_weight=W_PHOTO, smooth_loss_weight=W_SMOOTH, geometry_consistency_weight=W_GEOM,
                           num_scales=1, with_ssim=1, with_mask=1, with_auto_mask=1, padding_mode="zeros", world=world,
-                          exact_mask_normalisation=False)
+                          exact_mask_normalisation=bool(getattr(args, "exact", 0)))
+    if targs.exact_mask_normalisation and dist_on:
+        from scsfm_hip import dist as hip_dist
+        hip_dist.enable_exact_normalisation()
     disp_net = models.DispResNet(args.resnet_layers, False).to(device).train()
     pose_net = models.PoseResNet(18, False).to(device).train()
     n_grad = 0
-    if world > 1:
+    if dist_on:
         T.freeze_unused_scale_heads(disp_net, targs.num_scales)
         disp_net, pose_net = T.wrap_ddp(disp_net, dev_index), T.wrap_ddp(pose_net, dev_index)
     params = [{"params": [p for p in disp_net.parameters() if p.requires_grad]},
@@ -194,7 +197,7 @@ def e2e_train(args, device, world, dev_index, barrier):
     barrier()
     dt = time.perf_counter() - t0
     ranks = 1
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -206,6 +209,8 @@ def e2e_train(args, device, world, dev_index, barrier):
     if not (final == final and abs(final) < 1e6):
         raise RuntimeError(f"training diverged in the bench: loss {final}")
     del disp_net, pose_net, opt
+    if targs.exact_mask_normalisation and dist_on:
+        hip_dist.disable_exact_normalisation()  # (the hot-path legs below time the default mode)
     return {"elapsed_s": dt, "ranks": ranks, "final_loss": final, "trainable_parameters": n_grad,
             "model": f"DispResNet{args.resnet_layers} + PoseResNet18, random init, fp32 (MIOpen convolutions)"}
 
@@ -266,8 +271,12 @@ def library_identity(lib):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     blob = open(lib.path, "rb").read()
+    from scsfm_hip import build as hip_build
+    assert h.hexdigest()[:16] == hip_build.source_id()
     return {"path": os.path.realpath(lib.path), "abi_version": int(lib._dll.scsfm_abi_version()), "bytes": len(blob),
             "so_sha256_16": hashlib.sha256(blob).hexdigest()[:16], "source_sha256_16": h.hexdigest()[:16],
+            # what the binary itself says it was built from (scsfm_source_id): the loader rebuilds or refuses on a mismatch
+            "source_id_in_binary": lib.source_id(),
             "env_override": bool(os.environ.get("SCSFM_HIP_LIB"))}
 
 
@@ -295,6 +304,11 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="1: also time the hot-path step as a HIP-graph replay (scsfm_hip.graphs.GraphedStep) when "
                          "running on one GPU, 2: also under torchrun, 0: eager launches only")
+    ap.add_argument("--force-dist", default="none", choices=["none", "nccl", "gloo"],
+                    help="with one rank: still create a process group of this backend, wrap the nets in "
+                         "DistributedDataParallel and run every collective of the multi-GPU path (world size 1)")
+    ap.add_argument("--exact", type=int, default=0, help="1: exact mask normalisation (scsfm_hip.dist: one all-reduce of "
+                                                         "the pairs' raw sums per step) in the distributed legs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -313,11 +327,15 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     backend = None
-    if world > 1:
+    # --force-dist nccl|gloo: a process group, DistributedDataParallel and every collective of the N > 1 path at world
+    # size 1 -- what a 1-GPU box can verify of it (RCCL communicator, bucketed gradient all-reduce, exact-mode all-reduce)
+    dist_on = world > 1 or args.force_dist != "none"
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "gloo" if shared_gpu else "nccl"
-        if shared_gpu:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        backend = "gloo" if shared_gpu else ("nccl" if world > 1 else args.force_dist)
+        if backend == "gloo":
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
@@ -328,12 +346,13 @@ def main():
     assert lib.path.endswith(".so") and os.path.exists(lib.path)  # the HIP library, never a fallback
     ident = library_identity(lib)
     assert ident["abi_version"] == _lib.ABI_VERSION, ident
+    assert ident["env_override"] or ident["source_id_in_binary"] == ident["source_sha256_16"], ident
 
     flags = (1, 1, 1, "zeros")  # with_ssim, with_mask, with_auto_mask, padding_mode (scripts/train_resnet18_depth_256.sh)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -343,12 +362,12 @@ def main():
     e2e = None
     if args.e2e:
         try:
-            e2e = e2e_train(args, device, world, dev_index, barrier)
+            e2e = e2e_train(args, device, world, dev_index, barrier, dist_on)
         except Exception as exc:
             import traceback
             traceback.print_exc()
             log(f"bench.py: the training step failed: {type(exc).__name__}: {exc}")
-            if world > 1:
+            if dist_on:
                 try:
                     dist.destroy_process_group()
                 except Exception:
@@ -373,7 +392,7 @@ def main():
             o = step_fn()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             t = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
@@ -406,7 +425,7 @@ def main():
     except Exception as exc:
         single = {"error": f"{type(exc).__name__}: {exc}"}
     graph_err = None
-    if args.graph and (world == 1 or args.graph > 1):
+    if args.graph and ((world == 1 and not dist_on) or args.graph > 1):
         # the same step captured once into a HIP graph and replayed: identical kernels and results, one launch
         # (multi-process runs keep to eager launches unless --graph 2: at configs[1] the two agree, and capture
         # next to RCCL's watchdog thread is not something this repo can test on a 1-GPU box)
@@ -425,7 +444,7 @@ def main():
     loss, photo, smooth, geom = gvals
 
     # extension leg as a graph replay
-    if single is not None and "error" not in single and args.graph and (world == 1 or args.graph > 1):
+    if single is not None and "error" not in single and args.graph and ((world == 1 and not dist_on) or args.graph > 1):
         try:
             from scsfm_hip.graphs import GraphedStep
             gs1 = GraphedStep(lambda: hot_path_step_single_node(LF, x, flags))
@@ -480,7 +499,8 @@ def main():
                 args.resnet_layers == 18 else f"train images/sec (+ warp-loss ms/step) {args.dataset} {args.height}x{args.width} RN{args.resnet_layers}"
             parallelism = (f"ddp{world}: one process per GPU, DistributedDataParallel, bucketed {backend} all-reduce of "
                            f"{e2e['trainable_parameters'] * 4 / 1e6:.1f} MB of fp32 gradients per step; loss path sharded "
-                           f"by batch, no loss-path collective") if world > 1 else "1 GPU"
+                           f"by batch, " + ("one all-reduce of the pairs' raw sums per step (exact mask normalisation)"
+                                           if args.exact else "no loss-path collective")) if dist_on else "1 GPU"
         else:  # --e2e 0 (profiling): say plainly that this is NOT the training rate
             value, ms_per_step = hot_rate, loss_ms
             metric = "images/sec through the warp+loss hot path ONLY (--e2e 0: nets and optimizer not run)"
@@ -491,8 +511,10 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": parallelism},
-            "rccl_ranks": e2e["ranks"] if e2e is not None else world,
+            # ranks an all-reduce on the process group actually spanned: `rccl_ranks` only when that group is nccl (= RCCL)
+            ("rccl_ranks" if backend in (None, "nccl") else "collective_ranks"): e2e["ranks"] if e2e is not None else world,
             "collective_backend": backend,
+            "exact_mask_normalisation": bool(args.exact),
             "train": None if e2e is None else {"train_images_per_sec": round(value, 2), "ms_per_step": round(ms_per_step, 3),
                                                "final_loss": e2e["final_loss"], "model": e2e["model"],
                                                "trainable_parameters": e2e["trainable_parameters"]},
@@ -515,7 +537,7 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

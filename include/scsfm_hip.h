@@ -60,8 +60,12 @@ extern "C" {
 /* ABI version of this header; bumped on any change of a signature or of what an entry point does with its
  * buffers (2: the batched backwards store their depth gradients; scratch holds six planes.  3: scsfm_smooth_multi_bwd
  * takes `accumulate`; scsfm_step_total / scsfm_step_weights; scsfm_pair_desc::total.  4: scsfm_pixel2cam_*, scsfm_cam2pixel_*,
- * SCSFM_ROT_QUAT_FLAG for the warp entry points.  5: scsfm_pair_desc::depth_shift). */
+ * SCSFM_ROT_QUAT_FLAG for the warp entry points.  5: scsfm_pair_desc::depth_shift.  6: scsfm_pair_desc::hint,
+ * scsfm_source_id). */
 int scsfm_abi_version(void);
+/* Identity of the sources this binary was built from: the first 16 hex digits of the sha256 over csrc/ and this header
+ * (scsfm_hip/build.py: source_id(); "unknown" for a build that did not record it), NUL-terminated into buf[n]. */
+int scsfm_source_id(char* buf, size_t n);
 
 /* ---------------------------------------------------------------------------------------------
  * compute_pairwise_loss (loss_functions.py:95-119) incl. inverse_warp2 (inverse_warp.py:230-269),
@@ -154,6 +158,12 @@ typedef struct scsfm_pair_desc {
   void* total; /* read from d[0] only, may be NULL: 2 elements (device, store) that the forward fills with the
                   sums over all n pair-directions of out[0] (photo) and out[1] (geometry) -- what
                   compute_photo_and_geometry_loss returns (loss_functions.py:89-92) -- without a launch of its own */
+  void* hint; /* read from d[0] only, may be NULL: 2 doubles on the device = the (w_photo, w_geom) the speculative forward
+                 assumes the upstream gradients will stand in.  With it the forward ignores the host values of
+                 scsfm_pairs_fwd (beyond "speculate at all": a non-NULL gbuf) and reads the pair from here, and every
+                 scsfm_pairs_bwd leaves the upstream gradients it actually saw in it: whatever weights a training loop
+                 uses (train.py:268), the step after the first one speculates on the right ratio -- no host
+                 round trip, capturable in a HIP graph.  The caller owns the two doubles and initialises them */
   int depth_shift; /* 0: tgt_depth / ref_depth (and their gradient buffers) are [B,1,H,W].  s > 0: they are the maps of
                       a coarser scale, [B,1,H>>s,W>>s] with H, W multiples of 2^s, and the kernels read them through
                       the index map of F.interpolate(..., (H, W), mode='nearest') (loss_functions.py:77-82) instead of a

@@ -22,6 +22,8 @@ maps_<set>.npz   : the four maps of inverse_warp2 for both padding modes.
 total_<set>.npz  : compute_photo_and_geometry_loss (+ compute_smooth_loss) over 2 refs at 1 and 2
                    scales, with gradients w.r.t. every depth map and pose.
 misc.npz         : pose_vec2mat (euler, quat) values + gradients; compute_errors (kitti, nyu).
+cfg1_reference.npz : BASELINE.json configs[1] size (12 x 256 x 832): losses, gradient checksums and samples (gen_cfg1).
+transforms_reference.npz : hashes of the reference's training transform chain's outputs (gen_transforms).
 """
 import os
 import sys
@@ -32,11 +34,12 @@ import torch
 REF = "/root/reference"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.dont_write_bytecode = True
-sys.path.insert(0, REF)
-sys.path.insert(0, os.path.join(ROOT, "sc-sfmlearner-release_amd"))
+sys.path.insert(0, os.path.join(ROOT, "sc-sfmlearner-release_amd"))  # for scsfm_hip.synth (seeded inputs) only
+sys.path.insert(0, REF)                                               # the reference's modules win every shared name
 
 import inverse_warp as ref_warp  # noqa: E402  (reference, read-only)
 import loss_functions as ref_loss  # noqa: E402
+assert os.path.dirname(os.path.abspath(ref_loss.__file__)) == REF and os.path.dirname(os.path.abspath(ref_warp.__file__)) == REF
 from scsfm_hip import synth  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -178,6 +181,63 @@ def gen_misc():
     np.savez_compressed(os.path.join(OUT, "misc.npz"), **blob)
 
 
+def gen_cfg1():
+    """BASELINE.json configs[1] size (12 x 256 x 832, 2 refs, SSIM + mask + auto-mask, zeros): the unmodified
+    reference's three losses and, for L = 1.0 photo + 0.1 smooth + 0.5 geom, checksums of every gradient (sum, sum of
+    magnitudes, l2 norm, projection on the probe vector; fp64 accumulation), a strided sample of the depth gradients
+    and the pose gradients in full.  The inputs are synth.make_batch(12, 256, 832, n_ref=2, seed=101): seeded CPU
+    generators, reproducible wherever the test runs."""
+    d = synth.make_batch(12, 256, 832, n_ref=2, seed=101, depth="smooth", image="smooth", dataset="kitti")
+    td = [leaf(x) for x in d["tgt_depth"]]
+    rd = [[leaf(x) for x in r] for r in d["ref_depths"]]
+    ps, pi = [leaf(p) for p in d["poses"]], [leaf(p) for p in d["poses_inv"]]
+    photo, geom = ref_loss.compute_photo_and_geometry_loss(d["tgt_img"], d["ref_imgs"], d["intrinsics"], td, rd, ps, pi, 1,
+                                                           1, 1, 1, "zeros")
+    smooth = ref_loss.compute_smooth_loss(td, d["tgt_img"], rd, d["ref_imgs"])
+    (W_PHOTO * photo + W_SMOOTH * smooth + W_GEOM * geom).backward()
+    blob = {"photo": npy(photo), "geom": npy(geom), "smooth": npy(smooth),
+            "input_check": np.array([float(d["tgt_img"].double().sum()), float(d["tgt_depth"][0].double().sum()),
+                                     float(d["poses"][0].double().sum())])}
+    for name, t in [("g_tgt_depth", td[0])] + [(f"g_ref{i}_depth", rd[i][0]) for i in range(2)]:
+        g = t.grad.double().reshape(-1)
+        blob[f"{name}/checks"] = np.array([float(g.sum()), float(g.abs().sum()), float(g.norm()),
+                                           float((g * probe(g.numel()).double()).sum()), float(g.abs().max())])
+        blob[f"{name}/sample"] = npy(t.grad.reshape(-1)[::997])
+    for i in range(2):
+        blob[f"g_pose{i}"] = npy(ps[i].grad)
+        blob[f"g_pose_inv{i}"] = npy(pi[i].grad)
+    np.savez_compressed(os.path.join(OUT, "cfg1_reference.npz"), **blob)
+
+
+def gen_transforms():
+    """The reference's training transform chain (train.py:95-100, custom_transforms.py:33-84 -- imported unmodified) on
+    seeded uint8 frames of two BASELINE shapes: sha256 of every output image's float32 bytes and the updated
+    intrinsics.  tests/test_augment.py compares the device transform against these hashes: equal hash = byte-exact."""
+    import hashlib
+    import random
+    import custom_transforms as ref_ct  # (the reference's: /root/reference is first on sys.path)
+    assert os.path.dirname(os.path.abspath(ref_ct.__file__)) == REF
+    blob = {}
+    for S, T, H, W, seed in ((2, 3, 256, 832, 21), (2, 5, 256, 320, 22)):
+        rng = np.random.default_rng(seed)
+        frames = rng.integers(0, 256, size=(S, T, H, W, 3), dtype=np.uint8)
+        K = np.tile(np.array([[0.58 * W, 0, 0.5 * W], [0, 1.92 * H, 0.47 * H], [0, 0, 1]], dtype=np.float32), (S, 1, 1))
+        random.seed(seed)
+        np.random.seed(seed)
+        tf = ref_ct.Compose([ref_ct.RandomHorizontalFlip(), ref_ct.RandomScaleCrop(), ref_ct.ArrayToTensor(),
+                             ref_ct.Normalize(mean=[0.45, 0.45, 0.45], std=[0.225, 0.225, 0.225])])
+        key = f"{S}x{T}x{H}x{W}_seed{seed}"
+        hashes, Ks = [], []
+        for s in range(S):
+            imgs, k = tf([frames[s, t].astype(np.float32) for t in range(T)], np.copy(K[s]))
+            hashes += [hashlib.sha256(np.ascontiguousarray(im.numpy()).tobytes()).hexdigest() for im in imgs]
+            Ks.append(k)
+        blob[f"{key}/sha256"] = np.array(hashes)
+        blob[f"{key}/K"] = np.stack(Ks)
+        blob[f"{key}/frames_sha256"] = np.array([hashlib.sha256(frames.tobytes()).hexdigest()])
+    np.savez_compressed(os.path.join(OUT, "transforms_reference.npz"), **blob)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -190,6 +250,8 @@ def main():
             gen_maps(name, d)
             gen_total(name, d)
     gen_misc()
+    gen_cfg1()
+    gen_transforms()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

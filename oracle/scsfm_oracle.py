@@ -343,3 +343,83 @@ def depth_errors(gt, pred, dataset):
                 (r < 1.25 ** 3).float().mean()]
         tot = [t + v for t, v in zip(tot, vals)]
     return [float(t) / B for t in tot]
+
+
+# --------------------------------------------------------------------------------------------
+# Where an fp32 evaluation may legitimately differ from an fp64 one by more than round-off
+# --------------------------------------------------------------------------------------------
+def pairwise_gate_margins(tgt_img, ref_img, tgt_depth, ref_depth, pose, K, with_ssim, with_mask, with_auto_mask,
+                          padding_mode, eps_px=2e-3, eps_val=2e-4):
+    """The path is full of discontinuous gates (inverse_warp.py:219-224,264; loss_functions.py:99,101,104-105; the clamps
+    of the SSIM module :42; the tap switch of grid_sample).  A pixel whose gate is decided by less than fp32 round-off
+    can come out on the other side in ANY fp32 evaluation, the reference's own included, and then differs by its full
+    value.  This returns, per target pixel of one pair-direction (evaluate in fp64):
+
+        hard  [B,H,W] bool : the warped VALUE is discontinuous here (valid / overwrite gate, Z' clamp): it reaches the
+                             SSIM statistics of the 3x3 neighbours and through them the gradients of the 5x5
+        soft  [B,H,W] bool : a coefficient of this pixel is discontinuous (clamps of |It - Iw|, sign at 0, auto-mask
+                             comparison, SSIM clamp, depth-inconsistency sign / clamp): 3x3 of gradients
+        own   [B,H,W] bool : only this pixel's own dense gradient is discontinuous (sampling position within eps of a
+                             tap switch: the bilinear slope changes, values and scatter weights do not)
+        xa, ya [B,H,W] long: north-west tap of the pixel (clamped into the image), for the scatter footprint
+    """
+    assert tgt_img.dtype == torch.float64
+    B, _, H, W = tgt_img.shape
+    Kinv = inv3x3(K, "explicit")
+    cam = back_project(tgt_depth.squeeze(1), Kinv)
+    P = K @ pose_vec2mat(pose)
+    p = P[:, :, :3] @ cam.reshape(B, 3, -1) + P[:, :, 3:]
+    X, Y, Zr = p[:, 0].reshape(B, H, W), p[:, 1].reshape(B, H, W), p[:, 2].reshape(B, H, W)
+    Z = Zr.clamp(min=Z_MIN)
+    xn = 2 * (X / Z) / (W - 1) - 1
+    yn = 2 * (Y / Z) / (H - 1) - 1
+    # margins in pixels of the sampling position
+    hard = ((xn.abs() - 1).abs() * (W / 2) < eps_px) | ((yn.abs() - 1).abs() * (H / 2) < eps_px)
+    hard |= (Zr - Z_MIN).abs() < 1e-5
+    ix = ((xn + 1) * W - 1) / 2
+    iy = ((yn + 1) * H - 1) / 2
+    if padding_mode == "border":
+        hard |= (ix.abs() < eps_px) | ((ix - (W - 1)).abs() < eps_px) | (iy.abs() < eps_px) | ((iy - (H - 1)).abs() < eps_px)
+        ix, iy = ix.clamp(0, W - 1), iy.clamp(0, H - 1)
+    inside = (xn.abs() <= 1) & (yn.abs() <= 1) if padding_mode == "zeros" else torch.ones_like(hard)
+    fx, fy = ix - ix.floor(), iy - iy.floor()
+    own = inside & ((torch.minimum(fx, 1 - fx) < eps_px) | (torch.minimum(fy, 1 - fy) < eps_px))
+    warped, valid, proj_depth, comp_depth = inverse_warp2(ref_img, tgt_depth, ref_depth, pose, K, padding_mode, "explicit")
+    d = tgt_img - warped
+    soft = ((d.abs() < eps_val) | ((d.abs() - 1).abs() < eps_val)).any(dim=1)
+    if with_auto_mask:
+        ident = (tgt_img - ref_img).abs().mean(dim=1)
+        soft |= (d.abs().clamp(0, 1).mean(dim=1) - ident).abs() < eps_val
+    if with_ssim:
+        # (1 - SSIM)/2 before its clamp
+        xp, yp = _reflect_pad1(tgt_img), _reflect_pad1(warped)
+        mu_x, mu_y = _box3(xp), _box3(yp)
+        sig_x, sig_y = _box3(xp ** 2) - mu_x ** 2, _box3(yp ** 2) - mu_y ** 2
+        sig_xy = _box3(xp * yp) - mu_x * mu_y
+        raw = (1 - (2 * mu_x * mu_y + SSIM_C1) * (2 * sig_xy + SSIM_C2) / ((mu_x ** 2 + mu_y ** 2 + SSIM_C1) * (sig_x + sig_y + SSIM_C2))) / 2
+        soft |= ((raw.abs() < eps_val) | ((raw - 1).abs() < eps_val)).any(dim=1)
+    dd = (comp_depth - proj_depth).abs() / (comp_depth + proj_depth)
+    # (a pixel that samples nothing has projected depth 0 and diff_depth == 1 exactly, in any precision: no hazard)
+    soft |= ((dd < eps_val) | (((dd - 1).abs() < eps_val) & (proj_depth != 0))).squeeze(1)
+    xa = ix.floor().clamp(0, W - 2).long()
+    ya = iy.floor().clamp(0, H - 2).long()
+    return {"hard": hard, "soft": soft, "own": own, "xa": xa, "ya": ya}
+
+
+def _dilate(mask, r):
+    return F.max_pool2d(mask.to(torch.float32).unsqueeze(1), 2 * r + 1, 1, r).squeeze(1) > 0
+
+
+def unsafe_gradient_entries(m):
+    """From pairwise_gate_margins: (dense, scatter) boolean maps [B,H,W] of the entries of dL/d tgt_depth and of
+    dL/d ref_depth of that pair-direction whose value may depend on which side an fp32 gate fell."""
+    dense = _dilate(m["hard"], 2) | _dilate(m["soft"], 1) | m["own"]
+    src = _dilate(m["hard"], 1) | m["soft"]          # target pixels whose scattered VALUE may have jumped
+    B, H, W = src.shape
+    scatter = torch.zeros(B, H * W, dtype=torch.bool)
+    b, y, x = src.nonzero(as_tuple=True)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            lin = (m["ya"][b, y, x] + dy) * W + (m["xa"][b, y, x] + dx)
+            scatter[b, lin] = True
+    return dense, scatter.reshape(B, H, W)

@@ -227,6 +227,18 @@ __device__ __forceinline__ int t_clampi(int x, int lo, int hi) { return x < lo ?
 __device__ __forceinline__ float t_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double t_sqrt(double x) { return sqrt(x); }
 
+#ifdef PROBE_TIMING  // tuning builds only (tools/march_timing.py): wave 0's clock at the stage boundaries of every chunk / tile
+constexpr int kProbeStamps = 24, kProbeChunks = 6, kProbeWgs = 4096;
+__device__ unsigned long long g_probe[kProbeWgs * kProbeChunks * kProbeStamps];
+#define STAMP(i)                                                                                             \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && probe_wg < kProbeWgs && probe_chunk < kProbeChunks)                              \
+      g_probe[(probe_wg * kProbeChunks + probe_chunk) * kProbeStamps + (i)] = __builtin_readcyclecounter();   \
+  } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------------
 // lane <- neighbouring lane (DPP wave shift; lanes without a neighbour read 0).  The compiler folds the shift into
 // the consuming add / fmac (v_add_f32_dpp ... wave_shr:1); half-rate VALU, no LDS traffic.

@@ -242,7 +242,8 @@ __device__ __forceinline__ void publish_losses(double Sp, double Sg, double Sm, 
 // compute_photo_and_geometry_loss returns -- finished by whichever block comes last, in pair order.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb, int nblocks, int nblk_img, double spec,
-                                                                 double w_photo, double w_geom, T* total, int first) {
+                                                                 double w_photo, double w_geom, T* total, int first,
+                                                                 const double* __restrict__ hint) {
   __shared__ double red[3 * (kThreads / kWave)];
   const PairArgs<T>& pa = pb.p[blockIdx.x];
   const double* __restrict__ partials = pa.partials;
@@ -255,6 +256,10 @@ __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb
   block_sum<3>(v, red);
   if (threadIdx.x == 0) {
     publish_losses(v[0], v[1], v[2], sums, out);
+    if (hint && spec != 0.0) {  // the weights the speculative forward read from the device (scsfm_pair_desc::hint)
+      w_photo = hint[0]; w_geom = hint[1];
+      if (w_photo == 0.0) spec = 0.0;  // nothing to factor out: the backward runs its own passes
+    }
     sums[8] = spec; sums[9] = w_photo; sums[10] = w_geom;
     sums[11] = double(nblk_img);  // partial records per image the forward left (the pose reduction of the backward reads them)
     if (total) {
@@ -333,18 +338,32 @@ __device__ __forceinline__ unsigned pairs_to_run(const PairBatch<T>& pb, int npa
 constexpr unsigned kRuntimeFlags = 0xffffffffu;
 constexpr unsigned kTrainFlags = SCSFM_WITH_SSIM | SCSFM_WITH_MASK | SCSFM_WITH_AUTO_MASK;  // zeros padding
 }  // namespace scsfm
-#include "scsfm_march.h"  // the speculative forward proper (needs PairArgs / PairBatch / the plane indices above)
+#include "scsfm_spec_tile.h"  // the speculative forward proper (needs PairArgs / PairBatch / the plane indices above)
+#ifdef SCSFM_WITH_MARCH       // tuning / test builds only (tools/build_variants.sh, tests/hostsim): the column-march
+#include "scsfm_march.h"      // variant of the speculative forward, selected at run time with SCSFM_SPEC_KERNEL=march
+#endif
 namespace scsfm {
 
-#ifndef SCSFM_MARCH_WAVES_PER_SIMD  // tuning knob: waves per SIMD the speculative forward is compiled for (128 VGPRs at 4)
-#define SCSFM_MARCH_WAVES_PER_SIMD 4
-#endif
-// The speculative forward: one (band, segment) of a (pair, batch element) per workgroup, XCD-aware order.
+// The speculative forward: one tile per workgroup, XCD-aware order.
 template <typename T, bool kSsim, unsigned kFlags = kRuntimeFlags, bool kScaled = false>
-__global__ __launch_bounds__(March<T>::kWaves * kWave, sizeof(T) == 4 ? SCSFM_MARCH_WAVES_PER_SIMD : 1) void pair_fwd_spec_kernel(
-    PairBatch<T> pb, int B, int H, int W, unsigned flags, T r_hint, int seg_rows) {
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) void pair_fwd_spec_kernel(PairBatch<T> pb, int B, int H, int W,
+                                                                                  unsigned flags, T r_hint,
+                                                                                  const double* __restrict__ hint) {
+  if (hint) r_hint = hint[0] != 0.0 ? T(3.0 * hint[1] / hint[0]) : T(0);  // (scsfm_pair_desc::hint: the device's pair wins)
+  spec_tile<T, kSsim, kScaled, kFlags>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, pb, B, H, W, flags, nullptr, nullptr, r_hint);
+}
+#ifdef SCSFM_WITH_MARCH
+#ifndef SCSFM_MARCH_WAVES_PER_SIMD  // waves per SIMD the march is compiled for (168 VGPRs at 3: no spills; 128 at 4: spills)
+#define SCSFM_MARCH_WAVES_PER_SIMD 3
+#endif
+// ... and as a column march: one (band, segment) of a (pair, batch element) per workgroup (SCSFM_SPEC_KERNEL=march).
+template <typename T, bool kSsim, unsigned kFlags = kRuntimeFlags, bool kScaled = false>
+__global__ __launch_bounds__(March<T>::kWaves * kWave, sizeof(T) == 4 ? SCSFM_MARCH_WAVES_PER_SIMD : 1) void pair_march_kernel(
+    PairBatch<T> pb, int B, int H, int W, unsigned flags, T r_hint, int seg_rows, const double* __restrict__ hint) {
+  if (hint) r_hint = hint[0] != 0.0 ? T(3.0 * hint[1] / hint[0]) : T(0);
   march_segment<T, kSsim, kScaled, kFlags>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, seg_rows, pb, B, H, W, flags, r_hint);
 }
+#endif
 
 // One tile of pass A (blk = logical tile of an nbx x nby x (pairs * B) tiling).
 template <typename T, bool kSsim, bool kScaled>
@@ -649,8 +668,9 @@ __device__ __forceinline__ void retire_speculation(double* __restrict__ sums, co
 // forward, or the geometry pass).
 template <typename T>
 __global__ void pairs_pose_reduce_kernel(PairBatch<T> pb, int B, int nblk_geom, const T* __restrict__ K,
-                                         const T* __restrict__ g_photo, const T* __restrict__ g_geom) {
+                                         const T* __restrict__ g_photo, const T* __restrict__ g_geom, double* __restrict__ hint) {
   const int pair = blockIdx.x / B, b = blockIdx.x - pair * B;
+  if (hint && blockIdx.x == 0 && threadIdx.x == 0) { hint[0] = double(g_photo[0]); hint[1] = double(g_geom[0]); }
   const PairArgs<T>& pa = pb.p[pair];
   const bool spec = spec_valid(pa.sums, g_photo, g_geom);
   pose_reduce_one(b, spec ? int(pa.sums[11]) : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K, pa.gPp,
@@ -705,7 +725,10 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T> cb, size_t n, PairBatch<T> pb, int npairs,
                                                                  int B, int nblk_geom,
                                                                  const T* __restrict__ K, const T* __restrict__ g_photo,
-                                                                 const T* __restrict__ g_geom) {
+                                                                 const T* __restrict__ g_geom, double* __restrict__ hint) {
+  // The upstream gradients this backward saw are what the next forward speculates on (scsfm_pair_desc::hint; nothing
+  // in this launch or before it on the stream reads the two doubles any more: the forward kernels did).
+  if (hint && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { hint[0] = double(g_photo[0]); hint[1] = double(g_geom[0]); }
   // row 0 of the grid is dispatched first: the pose waves (one latency-bound reduction each) start at once and
   // finish under the streaming rows instead of after them
   const int d = (int)blockIdx.y - 1;
@@ -865,6 +888,17 @@ static unsigned debug_extra_lds() {
   }();
   return bytes;
 }
+// Which kernel serves the speculative forward: the tile kernel, or -- in builds that carry it -- the column march
+// (SCSFM_SPEC_KERNEL=march, for A/B measurements; read per launch).
+static bool spec_uses_march() {
+#ifdef SCSFM_WITH_MARCH
+  const char* e = getenv("SCSFM_SPEC_KERNEL");
+  return e && e[0] == 'm';
+#else
+  return false;
+#endif
+}
+#ifdef SCSFM_WITH_MARCH
 // Rows of a segment of the speculative forward's column march (scsfm_march.h).  A segment costs 4 extra warped rows
 // and a last, mostly idle chunk, so segments should be long; the launch should still be many times the 1024
 // workgroups the chip holds (4 per CU), so they cannot be too long.  SCSFM_MARCH_ROWS overrides (tests, tuning).
@@ -879,11 +913,12 @@ static int march_seg_rows(int H, int chunk, int units) {
   rows = ceil_div(rows, chunk) * chunk;
   return rows < H ? rows : ceil_div(H, chunk) * chunk;
 }
+#endif
 
 // Forward of up to kMaxPairs pair-directions per launch.  `spec`: every pair has a gbuf and w_photo != 0.
 template <typename T>
 static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags, bool spec,
-                           double w_photo, double w_geom, T* total, bool first, hipStream_t stream) {
+                           double w_photo, double w_geom, T* total, bool first, const double* hint, hipStream_t stream) {
   PairBatch<T> pb;
   for (int i = 0; i < n; ++i) pb.p[i] = make_pair_args<T>(d[i], B, H, W, nullptr, i);
   const bool kernel_only = (flags & SCSFM_DEBUG_KERNEL_ONLY) != 0;  // profiling: consts are in place already
@@ -895,22 +930,35 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
     const size_t npx = (size_t)B * H * W;
     if (!kernel_only)
       hipLaunchKernelGGL((pairs_zero_prep_kernel<T>), dim3(1024, n), dim3(kThreads), 0, stream, pb, npx, n, B, K);
-    const T r_hint = T(3.0 * w_geom / w_photo);
+    const T r_hint = w_photo != 0.0 ? T(3.0 * w_geom / w_photo) : T(0);
     const bool timed = g_profile.used < g_profile.n;
     if (timed) (void)hipEventRecord(g_profile.start[g_profile.used], stream);
-    {
-      const int nbands = ceil_div(W, kBandOut);
-      const int rows = march_seg_rows(H, March<T>::kStrip * March<T>::kWaves, nbands * n * B);
-      grid = dim3(nbands, ceil_div(H, rows), n * B);
+    if (!spec_uses_march()) {
+      grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
 #define SCSFM_LAUNCH_SPEC(...)                                                                                          \
-  hipLaunchKernelGGL((pair_fwd_spec_kernel<T, __VA_ARGS__>), grid, dim3(March<T>::kWaves * kWave), debug_extra_lds(), stream, pb, B, H, W, \
-                     flags & ~SCSFM_DEBUG_KERNEL_ONLY, r_hint, rows)
+  hipLaunchKernelGGL((pair_fwd_spec_kernel<T, __VA_ARGS__>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W, \
+                     flags & ~SCSFM_DEBUG_KERNEL_ONLY, r_hint, hint)
       if (!full_res && (flags & SCSFM_WITH_SSIM)) SCSFM_LAUNCH_SPEC(true, kRuntimeFlags, true);
       else if (!full_res) SCSFM_LAUNCH_SPEC(false, kRuntimeFlags, true);
       else if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags) SCSFM_LAUNCH_SPEC(true, kTrainFlags);
       else if (flags & SCSFM_WITH_SSIM) SCSFM_LAUNCH_SPEC(true);
       else SCSFM_LAUNCH_SPEC(false);
 #undef SCSFM_LAUNCH_SPEC
+    } else {
+#ifdef SCSFM_WITH_MARCH
+      const int nbands = ceil_div(W, kBandOut);
+      const int rows = march_seg_rows(H, March<T>::kStrip * March<T>::kWaves, nbands * n * B);
+      grid = dim3(nbands, ceil_div(H, rows), n * B);
+#define SCSFM_LAUNCH_SPEC(...)                                                                                          \
+  hipLaunchKernelGGL((pair_march_kernel<T, __VA_ARGS__>), grid, dim3(March<T>::kWaves * kWave), debug_extra_lds(), stream, pb, B, H, W, \
+                     flags & ~SCSFM_DEBUG_KERNEL_ONLY, r_hint, rows, hint)
+      if (!full_res && (flags & SCSFM_WITH_SSIM)) SCSFM_LAUNCH_SPEC(true, kRuntimeFlags, true);
+      else if (!full_res) SCSFM_LAUNCH_SPEC(false, kRuntimeFlags, true);
+      else if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags) SCSFM_LAUNCH_SPEC(true, kTrainFlags);
+      else if (flags & SCSFM_WITH_SSIM) SCSFM_LAUNCH_SPEC(true);
+      else SCSFM_LAUNCH_SPEC(false);
+#undef SCSFM_LAUNCH_SPEC
+#endif
     }
     if (timed) (void)hipEventRecord(g_profile.stop[g_profile.used++], stream);
   } else {
@@ -926,7 +974,8 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
   }
   if (!kernel_only)
     hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(n), dim3(kThreads), 0, stream, pb, (int)(grid.x * grid.y * B),
-                       (int)(grid.x * grid.y), spec ? 1.0 : 0.0, spec ? w_photo : 0.0, spec ? w_geom : 0.0, total, first ? 1 : 0);
+                       (int)(grid.x * grid.y), spec ? 1.0 : 0.0, spec ? w_photo : 0.0, spec ? w_geom : 0.0, total, first ? 1 : 0,
+                       spec ? hint : nullptr);
   return launch_status();
 }
 
@@ -939,12 +988,14 @@ static int pairs_fwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
     if (!desc_inputs_ok(d[i], H, W) || !d[i].out) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   // maximal runs of descriptors with the same mode (speculative or plain), at most kMaxPairs each
+  const double* hint = n > 0 ? (const double*)d[0].hint : nullptr;
+  const bool may_spec = w_photo != 0.0 || hint != nullptr;
   int i = 0;
   while (i < n) {
-    const bool spec = d[i].gbuf != nullptr && w_photo != 0.0;
+    const bool spec = d[i].gbuf != nullptr && may_spec;
     int j = i + 1;
-    while (j < n && j - i < kMaxPairs && ((d[j].gbuf != nullptr && w_photo != 0.0) == spec)) ++j;
-    int rc = pairs_fwd_chunk<T>(j - i, d + i, B, H, W, K, flags, spec, w_photo, w_geom, (T*)d[0].total, i == 0, stream);
+    while (j < n && j - i < kMaxPairs && ((d[j].gbuf != nullptr && may_spec) == spec)) ++j;
+    int rc = pairs_fwd_chunk<T>(j - i, d + i, B, H, W, K, flags, spec, w_photo, w_geom, (T*)d[0].total, i == 0, hint, stream);
     if (rc) return rc;
     i = j;
   }
@@ -999,7 +1050,7 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
     }
     if (flags & SCSFM_DEBUG_SKIP_GEOM) {
       hipLaunchKernelGGL((pairs_pose_reduce_kernel<T>), dim3(m * B), dim3(kWave), 0, stream, pb, B, nbx * nby, K, g_photo,
-                         g_geom);
+                         g_geom, (double*)d[0].hint);
     } else {
       // group the private planes by the caller's destination buffer: a pair's dense plane belongs to its
       // target depth map, its scatter plane to its reference depth map
@@ -1030,7 +1081,7 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
       gx = gx < gpose ? gpose : gx;
       // (+ 1 row of workgroups: dL/dpose)
       hipLaunchKernelGGL((pairs_combine_kernel<T>), dim3(gx, cb.nd + 1), dim3(kThreads), 0, stream, cb, npx, pb, m, B,
-                         nbx * nby, K, g_photo, g_geom);
+                         nbx * nby, K, g_photo, g_geom, (double*)d[0].hint);
       if (!full_res)
         hipLaunchKernelGGL((pairs_combine_pooled_kernel<T>), dim3(gx / 4 + 1, cb.nd), dim3(kThreads), 0, stream, cb, npx, W,
                            g_photo, g_geom);
@@ -1056,6 +1107,7 @@ static scsfm_pair_desc one_desc(const T* tgt_img, const T* ref_img, const T* tgt
   d.tgt_img = tgt_img; d.ref_img = ref_img; d.tgt_depth = tgt_depth; d.ref_depth = ref_depth; d.pose = pose;
   d.ws = ws; d.out = out; d.g_tgt_depth = g_tgt; d.g_ref_depth = g_ref; d.g_pose = g_pose; d.gbuf = gbuf;
   d.total = nullptr;
+  d.hint = nullptr;
   d.depth_shift = 0;
   return d;
 }

@@ -336,7 +336,19 @@ static int pose_bwd(int B, const T* vec, int mode, const T* g_mat, T* g_vec, voi
 
 extern "C" {
 
-int scsfm_abi_version(void) { return 5; }
+int scsfm_abi_version(void) { return 6; }
+
+#ifndef SCSFM_SOURCE_ID
+#define SCSFM_SOURCE_ID "unknown"
+#endif
+int scsfm_source_id(char* buf, size_t n) {
+  static const char id[] = SCSFM_SOURCE_ID;
+  if (!buf || n == 0) return SCSFM_ERR_ARG;
+  size_t i = 0;
+  for (; i + 1 < n && id[i]; ++i) buf[i] = id[i];
+  buf[i] = 0;
+  return SCSFM_OK;
+}
 
 size_t scsfm_warp_ws_bytes(int B) {
   if (B <= 0) return 0;

@@ -100,10 +100,23 @@ def pixel2cam(depth, intrinsics_inv):
     return _ops.Pixel2Cam.apply(depth, intrinsics_inv)
 
 
+def _check_c2p(cam_coords, rot, tr):
+    """The kernels index the rotation as 9 and the translation as 3 contiguous scalars per batch element: any other shape
+    (a [B,3,4] matrix, a [B,3] vector, another batch size) would be read with the wrong stride where the reference's
+    matmul / broadcast raises.  Same message format as check_sizes (inverse_warp.py:20-26)."""
+    B = cam_coords.size(0)
+    if rot is not None:
+        check_sizes(rot, 'proj_c2p_rot', 'B33')
+        assert rot.size(0) == B, "wrong size for proj_c2p_rot, expected {}x3x3, got {}".format(B, list(rot.size()))
+    if tr is not None:
+        assert list(tr.size()) == [B, 3, 1], "wrong size for proj_c2p_tr, expected {}x3x1, got {}".format(B, list(tr.size()))
+
+
 def cam2pixel(cam_coords, proj_c2p_rot, proj_c2p_tr, padding_mode):
     """inverse_warp.py:47-74: camera coordinates [B,3,H,W], rotation [B,3,3] | None, translation [B,3,1] | None ->
     normalised sampling grid [B,H,W,2].  (``padding_mode`` is unused by the reference too.)"""
     check_sizes(cam_coords, 'cam_coords', 'B3HW')
+    _check_c2p(cam_coords, proj_c2p_rot, proj_c2p_tr)
     return _ops.Cam2Pixel.apply(0, False, cam_coords, proj_c2p_rot, proj_c2p_tr)
 
 
@@ -111,5 +124,6 @@ def cam2pixel2(cam_coords, proj_c2p_rot, proj_c2p_tr, padding_mode):
     """inverse_warp.py:194-227 -> (grid [B,H,W,2], computed depth [B,1,H,W]); under 'zeros' padding out-of-range
     coordinates are overwritten with 2 (and carry no gradient)."""
     check_sizes(cam_coords, 'cam_coords', 'B3HW')
+    _check_c2p(cam_coords, proj_c2p_rot, proj_c2p_tr)
     flags = _capi.C2P_OVERWRITE if padding_mode == 'zeros' else 0
     return _ops.Cam2Pixel.apply(flags, True, cam_coords, proj_c2p_rot, proj_c2p_tr)

@@ -23,7 +23,7 @@ HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "scsfm_
 # SCSFM_HIP_LIB points at a library built elsewhere (tuning variants, a system-wide install)
 LIB_PATH = os.environ.get("SCSFM_HIP_LIB") or os.path.join(HERE, "libscsfm_hip.so")
 
-ABI_VERSION = 5  # include/scsfm_hip.h
+ABI_VERSION = 6  # include/scsfm_hip.h
 
 _CTYPES = {"int": ctypes.c_int, "unsigned": ctypes.c_uint, "size_t": ctypes.c_size_t, "double": ctypes.c_double}
 _DECL = re.compile(r"^(int|size_t)\s+(scsfm_\w+)\s*\(([^)]*)\)\s*;", re.M | re.S)
@@ -71,6 +71,12 @@ class CLib:
         if self._dll.scsfm_abi_version() != ABI_VERSION:
             raise ScsfmError(f"{path}: ABI version mismatch")
 
+    def source_id(self):
+        """The source hash compiled into the binary (scsfm_hip/build.py: source_id)."""
+        buf = ctypes.create_string_buffer(64)
+        self._fn["scsfm_source_id"](buf, 64)
+        return buf.value.decode()
+
     def call(self, name, *args):
         """Invoke an int-returning entry point; raise on a non-zero status."""
         rc = self._fn[name](*args)
@@ -87,13 +93,32 @@ _lib = None
 
 
 def get() -> CLib:
-    """The HIP library (singleton).  Builds it with hipcc on first use if it is not there."""
+    """The HIP library (singleton).  Builds it with hipcc on first use if it is not there, and ties the binary to the
+    sources next to it: a library whose compiled-in source hash differs from the tree's is rebuilt, or -- without
+    hipcc -- refused (a library named by SCSFM_HIP_LIB, a tuning variant, is taken as it is)."""
     global _lib
     if _lib is None:
         with _lock:
             if _lib is None:
-                if not os.path.exists(LIB_PATH):
-                    from . import build as _build
+                from . import build as _build
+                own = "SCSFM_HIP_LIB" not in os.environ
+                if own and not os.path.exists(LIB_PATH):
                     _build.build()
-                _lib = CLib(LIB_PATH)
+                lib = CLib(LIB_PATH)
+                if own and lib.source_id() != _build.source_id():
+                    try:
+                        _build.build(force=True)
+                    except Exception as e:
+                        raise ScsfmError(f"{LIB_PATH} was built from other sources ({lib.source_id()}) than the tree's "
+                                         f"({_build.source_id()}) and cannot be rebuilt here: {e}") from e
+                    # (a shared object cannot be reloaded into the process under the same name: the stale copy stays
+                    # mapped, so the fresh one is opened through a unique temporary link)
+                    import tempfile
+                    link = os.path.join(tempfile.mkdtemp(prefix="scsfm_"), "libscsfm_hip.so")
+                    os.symlink(LIB_PATH, link)
+                    lib = CLib(link)
+                    lib.path = LIB_PATH
+                    if lib.source_id() != _build.source_id():
+                        raise ScsfmError(f"{LIB_PATH}: rebuilt, but its source id {lib.source_id()} is not the tree's")
+                _lib = lib
     return _lib

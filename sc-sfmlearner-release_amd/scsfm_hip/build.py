@@ -8,6 +8,7 @@ It is written next to this file so that it travels with the source tree to the G
 from __future__ import annotations
 
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -33,6 +34,16 @@ def deps():
         [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "scsfm_hip.h")]
 
 
+def source_id():
+    """First 16 hex digits of the sha256 over every file the library is built from (names and contents, sorted).  It is
+    compiled into the binary (scsfm_source_id) so that a loaded .so can be tied to the sources next to it."""
+    h = hashlib.sha256()
+    for path in deps():
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True
@@ -48,7 +59,7 @@ def build(force=False, verbose=True, extra=()):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libscsfm_hip.so cannot be built on this machine")
     tmp = LIB + ".tmp"
-    cmd = [hipcc, *FLAGS, *extra, "-o", tmp, *sources()]
+    cmd = [hipcc, *FLAGS, f'-DSCSFM_SOURCE_ID="{source_id()}"', *extra, "-o", tmp, *sources()]
     if verbose:
         print("[scsfm_hip.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

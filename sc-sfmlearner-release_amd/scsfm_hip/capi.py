@@ -280,7 +280,7 @@ import functools as _ft
 class PairDesc(_ct.Structure):
     """scsfm_pair_desc of include/scsfm_hip.h."""
     _fields_ = [(n, _ct.c_void_p) for n in ("tgt_img", "ref_img", "tgt_depth", "ref_depth", "pose", "ws", "out",
-                                            "g_tgt_depth", "g_ref_depth", "g_pose", "gbuf", "total")] + \
+                                            "g_tgt_depth", "g_ref_depth", "g_pose", "gbuf", "total", "hint")] + \
                [("depth_shift", _ct.c_int)]
 
 
@@ -329,7 +329,7 @@ def _pair_list(tgt_img, ref_imgs, tgt_depths, ref_depths, poses, poses_inv):
 
 
 def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, group=None,
-                       hint=None, ws=None):
+                       hint=None, ws=None, hint_dev=None):
     """All pair-directions of loss_functions.py:56-90 in ONE call into the library.  ``tgt_depths[s]``
     and ``ref_depths[i][s]`` are full-resolution maps or, for a coarser scale, [B, 1, H >> k, W >> k] maps that the
     kernels read through the nearest up-sampling's index map (`depth_shift`).  Returns (photo, geom, outs [n_pairs, 8], ws)
@@ -337,7 +337,10 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
 
     ``hint`` = (w_photo, w_geom): run the speculative forward (scsfm_pair_fwd_spec) -- the backward's
     tiled pass doubles as the forward and leaves its output planes in ``ws``'s tail for the backward,
-    valid if the upstream gradients later stand in that ratio (checked on the device).
+    valid if the upstream gradients later stand in that ratio (checked on the device).  ``hint_dev``: a float64[2]
+    tensor on the device holding that pair (scsfm_pair_desc::hint): the kernels read it instead of the host values, and
+    photo_geometry_bwd -- given the same tensor -- leaves the upstream gradients it saw in it, so that the next
+    forward speculates on the weights the training loop really uses.
 
     ``group``: a torch.distributed process group -> exact data-parallel mode: the three raw sums of
     every pair are all-reduced (one [n_pairs, 3] collective) and the masked means are re-evaluated on
@@ -362,6 +365,9 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
     outs = torch.empty(n + 1, 8, dtype=tgt_img.dtype, device=tgt_img.device)  # per pair; last row: the totals
     descs = (PairDesc * n)()
     descs[0].total = outs.data_ptr() + n * outs.element_size() * 8
+    if spec and hint_dev is not None:
+        assert hint_dev.dtype == torch.float64 and hint_dev.numel() == 2 and hint_dev.device == tgt_img.device
+        descs[0].hint = hint_dev.data_ptr()
     wp, op, esz = ws.data_ptr(), outs.data_ptr(), outs.element_size() * 8
     for j, (ti, ri, dt, dr, po, _, _) in enumerate(pairs):
         d = descs[j]
@@ -389,7 +395,7 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
 
 
 def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws, g_photo,
-                       g_geom):
+                       g_geom, hint_dev=None):
     """Gradients of photo_geometry_fwd's two sums: (g_tgt_depths[s], g_ref_depths[i][s], g_poses[i],
     g_poses_inv[i]).  Each depth map's gradient buffer receives the sum over every pair-direction that
     touches it (dense as target, scattered as reference) from the library's combining kernel, which
@@ -423,6 +429,8 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         return g_td[key[1]] if key[0] == "t" else g_rd[key[1]][key[2]]
 
     descs = (PairDesc * n)()
+    if hint_dev is not None:
+        descs[0].hint = hint_dev.data_ptr()
     wp, gp, psz = ws.data_ptr(), g_pose_all.data_ptr(), g_pose_all.element_size() * B * 6
     for j, (ti, ri, dt, dr, po, kt, kr) in enumerate(pairs):
         d = descs[j]

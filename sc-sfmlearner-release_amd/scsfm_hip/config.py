@@ -5,8 +5,12 @@ from __future__ import annotations
 # (train.py:268, defaults -p 1 -c 0.5 of scripts/train_resnet18_depth_256.sh).  With a hint the
 # forward of compute_photo_and_geometry_loss already runs the backward's tiled pass (speculative
 # forward, see include/scsfm_hip.h: scsfm_pair_fwd_spec).  A wrong hint costs time, never
-# correctness: the backward checks the actual upstream gradients on the device and recomputes.
+# correctness: the backward checks the actual upstream gradients on the device and recomputes --
+# and leaves them in the device-side copy of the hint (scsfm_pair_desc::hint), so the step after
+# a mis-speculated one already speculates on the weights the loop really uses.  set_weight_hint
+# is therefore an optimisation of the FIRST step only.
 _hint = (1.0, 0.5)
+_hint_dev = {}  # device -> float64[2] tensor holding (w_photo, w_geom); rewritten by every backward
 
 
 def set_weight_hint(w_photo, w_geom):
@@ -14,12 +18,29 @@ def set_weight_hint(w_photo, w_geom):
     global _hint
     if w_photo is None:
         _hint = None
+        _hint_dev.clear()
         return
     # the upstream gradients arrive as fp32 tensors: compare against the fp32 roundings of the weights
     # (the device-side check is an exact equality of products)
     import numpy as np
     _hint = (float(np.float32(w_photo)), float(np.float32(w_geom)))
+    for t in _hint_dev.values():
+        t.copy_(t.new_tensor(_hint))
 
 
 def weight_hint():
     return _hint
+
+
+def hint_tensor(device):
+    """The device-side (w_photo, w_geom) of ``device`` (created from the host hint on first use); None when speculation
+    is disabled."""
+    if _hint is None:
+        return None
+    import torch
+    key = (device.type, device.index)
+    t = _hint_dev.get(key)
+    if t is None:
+        t = torch.tensor(_hint, dtype=torch.float64, device=device)
+        _hint_dev[key] = t
+    return t

@@ -67,10 +67,12 @@ class PhotoGeometryLoss(torch.autograd.Function):
         ref_imgs, tgt_depths, ref_depths, poses, poses_inv, _ = PhotoGeometryLoss._split(rest, n_ref, n_scales)
         # speculate only when a backward can follow (some depth / pose requires grad)
         hint = _config.weight_hint() if any(ctx.needs_input_grad) else None
+        # the pair the kernels speculate on lives on the device: every backward leaves the upstream gradients it saw there
+        hint_dev = _config.hint_tensor(tgt_img.device) if hint is not None else None
         photo, geom, _, ws = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
-                                                     poses_inv, group=_dist.exact_group(), hint=hint)
+                                                     poses_inv, group=_dist.exact_group(), hint=hint, hint_dev=hint_dev)
         ctx.flags, ctx.n_ref, ctx.n_scales = flags, n_ref, n_scales
-        ctx.spec_hint = hint
+        ctx.hint_dev = hint_dev
         ctx.save_for_backward(tgt_img, K, *rest, ws)
         return photo, geom
 
@@ -83,36 +85,11 @@ class PhotoGeometryLoss(torch.autograd.Function):
         _no_grad_inputs(ctx, 3, ["tgt_img", "intrinsics"] + [f"ref_imgs[{i}]" for i in range(n_ref)])
         ref_imgs, tgt_depths, ref_depths, poses, poses_inv, n_in = PhotoGeometryLoss._split(saved[2:], n_ref, n_scales)
         ws = saved[2 + n_in]
-        _check_hint_once(ctx, g_photo, g_geom)
         g_td, g_rd, g_poses, g_poses_inv = capi.photo_geometry_bwd(
             lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws,
-            _scalar(g_photo, tgt_img), _scalar(g_geom, tgt_img))
+            _scalar(g_photo, tgt_img), _scalar(g_geom, tgt_img), hint_dev=ctx.hint_dev)
         return (None, None, None, None, None, *([None] * n_ref), *g_td, *[g for r in g_rd for g in r], *g_poses,
                 *g_poses_inv)
-
-
-_hint_checked = False
-
-
-def _check_hint_once(ctx, g_photo, g_geom):
-    """The first backward of a process compares the upstream gradients with the weight hint the forward speculated
-    on (one host read-back, once): a mismatch is never wrong -- the device falls back to its two backward passes --
-    but it costs ~0.5 ms per step at KITTI size, and a drop-in user with other loss weights should hear about it."""
-    global _hint_checked
-    if _hint_checked or not getattr(ctx, "spec_hint", None) or g_photo is None or g_geom is None:
-        return
-    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-        return  # (no host read-back inside a graph capture; checked on the next eager backward)
-    _hint_checked = True
-    wp, wg = ctx.spec_hint
-    gp, gg = float(g_photo), float(g_geom)
-    if abs(gp * wg - gg * wp) > 1e-6 * max(abs(gp * wg), abs(gg * wp), 1e-30):
-        import warnings
-        warnings.warn(f"scsfm_hip: the loss weights arriving in backward (photo {gp:g}, geometry {gg:g}) do not stand in "
-                      f"the ratio the forward speculated on ({wp:g} : {wg:g}); results are unaffected, but every step "
-                      "now runs the two-pass backward.  Call scsfm_hip.config.set_weight_hint(w_photo, w_geom) with the "
-                      "weights of `w1*loss_1 + w3*loss_3` (train.py:268), or set_weight_hint(None, None) to disable "
-                      "speculation.", RuntimeWarning, stacklevel=3)
 
 
 class PairwiseLoss(torch.autograd.Function):

@@ -86,7 +86,9 @@ parser.add_argument('--single-loss-node', type=int, default=1,
                     help='1: the two losses and their weighted sum behind one autograd node (extension; same values and '
                          'gradients, fewer launches), 0: the three reference-style calls')
 parser.add_argument('--exact-mask-normalisation', action='store_true',
-                    help='data parallel: all-reduce the mask sums so the loss equals the single-process loss on the global batch')
+                    help='data parallel: all-reduce the mask sums so the loss equals the single-process loss on the global batch. '
+                         '(BatchNorm running statistics stay per rank either way -- as per replica under the reference\'s '
+                         'nn.DataParallel, train.py:168-169 -- and rank 0\'s are the ones validated and checkpointed.)')
 
 best_error = -1
 n_iter = 0
@@ -174,6 +176,9 @@ def main():
     # -- every applicable solver compiled and timed for every convolution shape of both nets: more than 13 minutes before
     # the first step at 256x832 -- and the step it buys is not faster (tools/e2e_probe.py), so it is off unless asked for
     torch.backends.cudnn.benchmark = os.environ.get("SCSFM_CUDNN_BENCHMARK", "0") == "1"
+    if is_main:
+        print("=> torch.backends.cudnn.benchmark = {} (the reference sets True, train.py:83; on MIOpen that is an exhaustive "
+              "per-layer solver search: SCSFM_CUDNN_BENCHMARK=1 turns it on)".format(torch.backends.cudnn.benchmark))
 
     training_writer = _ScalarLog()
     output_writers = [_ScalarLog() for _ in range(3)] if args.log_output else []

@@ -9,7 +9,7 @@ import pytest
 from scsfm_hip import _lib
 
 EXPECTED = {
-    "scsfm_abi_version", "scsfm_profile_begin", "scsfm_profile_end",
+    "scsfm_abi_version", "scsfm_source_id", "scsfm_profile_begin", "scsfm_profile_end",
     "scsfm_step_total_f32", "scsfm_step_total_f64", "scsfm_step_weights_f32", "scsfm_step_weights_f64",
     "scsfm_pair_ws_bytes", "scsfm_pair_bwd_scratch_bytes", "scsfm_pair_fwd_f32", "scsfm_pair_bwd_f32", "scsfm_pair_refinalize_f32", "scsfm_pair_fwd_spec_f32",
     "scsfm_pair_fwd_spec_f64",

@@ -85,3 +85,55 @@ def test_device_transform_is_byte_exact_gpu():
     from scsfm_hip import _lib
     for S, T, H, W, seed in ((4, 3, 256, 832, 11), (3, 5, 256, 320, 12)):
         _check(_lib.get(), "cuda:0", S, T, H, W, seed)
+
+
+# ------------------------------------------------------------------------------------------------
+# fixtures recorded from the reference's own custom_transforms module (oracle/make_golden.py: gen_transforms)
+# ------------------------------------------------------------------------------------------------
+def _reference_cases():
+    import hashlib
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transforms_reference.npz"))
+    for key in sorted({k.split("/")[0] for k in z.files}):
+        dims, seed = key.split("_seed")
+        S, T, H, W = (int(v) for v in dims.split("x"))
+        rng = np.random.default_rng(int(seed))
+        frames = rng.integers(0, 256, size=(S, T, H, W, 3), dtype=np.uint8)
+        assert hashlib.sha256(frames.tobytes()).hexdigest() == str(z[f"{key}/frames_sha256"][0])  # same inputs as recorded
+        yield S, T, H, W, int(seed), frames, [str(h) for h in z[f"{key}/sha256"]], z[f"{key}/K"]
+
+
+def _hashes(images):
+    import hashlib
+    return [hashlib.sha256(np.ascontiguousarray(im.numpy()).tobytes()).hexdigest() for im in images]
+
+
+def test_host_transform_chain_reproduces_the_reference_fixture():
+    """This repo's custom_transforms (the loader workers' path) against the hashes recorded from the reference's module."""
+    import custom_transforms as mine
+    for S, T, H, W, seed, frames, want, K_want in _reference_cases():
+        K = np.tile(np.array([[0.58 * W, 0, 0.5 * W], [0, 1.92 * H, 0.47 * H], [0, 0, 1]], dtype=np.float32), (S, 1, 1))
+        random.seed(seed)
+        np.random.seed(seed)
+        tf = _chain(mine)
+        got = []
+        for s in range(S):
+            imgs, k = tf([frames[s, t].astype(np.float32) for t in range(T)], np.copy(K[s]))
+            got += _hashes(imgs)
+            assert np.array_equal(k, K_want[s])
+        assert got == want
+
+
+@pytest.mark.gpu
+def test_device_transform_reproduces_the_reference_fixture_gpu():
+    """The device transform (csrc/scsfm_augment.hip) on the GPU box, where /root/reference does not exist: every output
+    image hashes to what the reference's own transform chain produced in the build container -- byte-exact."""
+    from scsfm_hip import _lib
+    for S, T, H, W, seed, frames, want, K_want in _reference_cases():
+        K = np.tile(np.array([[0.58 * W, 0, 0.5 * W], [0, 1.92 * H, 0.47 * H], [0, 0, 1]], dtype=np.float32), (S, 1, 1))
+        random.seed(seed)
+        np.random.seed(seed)
+        recs = A.draw_params(S, H, W)
+        out = A.augment(torch.from_numpy(frames).to("cuda:0"), recs, lib=_lib.get()).cpu()  # [T, S, 3, H, W]
+        got = [h for s in range(S) for h in _hashes([out[t, s] for t in range(T)])]
+        assert got == want
+        assert np.array_equal(A.update_intrinsics(K, recs, W), K_want)

@@ -43,3 +43,23 @@ def test_every_public_name_runs_and_matches_the_oracle(monkeypatch):
     assert float((IW.quat2mat(ang) - O.rot_from_quat(ang)).abs().max()) < 1e-14
     with pytest.raises(AssertionError, match="wrong size for depth"):
         IW.pixel2cam(torch.zeros(2, 1, 4, 5), torch.zeros(2, 3, 3))
+
+
+def test_cam2pixel_rejects_matrices_the_kernels_would_misread():
+    """cam2pixel / cam2pixel2 index the rotation as 9 and the translation as 3 contiguous scalars per batch element: a
+    [B,3,4] matrix (the shape the reference's docstring names), a [B,3] translation or another batch size must raise
+    like check_sizes does -- before anything reaches the library (no device needed for this)."""
+    import pytest
+    import torch
+    import inverse_warp as IW
+    cam = torch.zeros(2, 3, 4, 5)
+    rot, tr = torch.eye(3).repeat(2, 1, 1), torch.zeros(2, 3, 1)
+    for fn in (IW.cam2pixel, IW.cam2pixel2):
+        with pytest.raises(AssertionError, match="wrong size for proj_c2p_rot"):
+            fn(cam, torch.zeros(2, 3, 4), tr, "zeros")
+        with pytest.raises(AssertionError, match="wrong size for proj_c2p_rot"):
+            fn(cam, torch.eye(3).repeat(3, 1, 1), tr, "zeros")
+        with pytest.raises(AssertionError, match="wrong size for proj_c2p_tr"):
+            fn(cam, rot, torch.zeros(2, 3), "zeros")
+        with pytest.raises(AssertionError, match="wrong size for cam_coords"):
+            fn(torch.zeros(2, 4, 5), rot, tr, "zeros")

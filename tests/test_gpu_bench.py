@@ -46,7 +46,10 @@ def test_single_gpu_line_has_the_contract_fields():
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["variants"]) >= 3
     assert {v["threads"] for v in cb["variants"]} >= {1} and any(v["anomaly_mode"] for v in cb["variants"])
     lib = r["library"]
-    assert lib["path"].endswith("scsfm_hip/libscsfm_hip.so") and lib["abi_version"] == 5 and not lib["env_override"]
+    assert lib["path"].endswith("scsfm_hip/libscsfm_hip.so") and lib["abi_version"] == 6 and not lib["env_override"]
+    # the binary names the sources it was built from, and they are the tree's
+    assert lib["source_id_in_binary"] == lib["source_sha256_16"] and len(lib["source_sha256_16"]) == 16
+    assert r["collective_backend"] is None and r["rccl_ranks"] == 1
 
 
 def test_two_ranks_sharing_the_gpu_report_a_training_rate():
@@ -55,6 +58,25 @@ def test_two_ranks_sharing_the_gpu_report_a_training_rate():
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--cpu-seconds", "0"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     r = _last_json(out)
-    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["config"]["global_batch"] == 4
+    # (gloo between the two ranks that share the GPU: the line says so and does not call them RCCL ranks)
+    assert r["n_gpus"] == 2 and r["collective_backend"] == "gloo" and r["collective_ranks"] == 2 and "rccl_ranks" not in r
+    assert r["config"]["global_batch"] == 4
     assert r["value"] > 0 and r["train"]["final_loss"] == r["train"]["final_loss"]
     assert "ddp2" in r["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("exact", [0, 1])
+def test_one_rank_over_rccl(exact):
+    """The multi-GPU path with an RCCL communicator under it, as far as one GPU can take it: process group on the nccl
+    backend (world size 1, device_id), both nets in DistributedDataParallel (bucketed gradient all-reduce on HIP tensors,
+    gradient_as_bucket_view), training steps in the default and in the exact mask-normalisation mode (all-reduce of the
+    pairs' raw sums on a HIP tensor + re-finalisation), the hot path eager and as a HIP-graph replay (--graph 2)."""
+    env = dict(os.environ, SCSFM_CUDNN_BENCHMARK="0", MIOPEN_FIND_MODE="FAST", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--cpu-seconds", "0", "--force-dist", "nccl",
+                          "--exact", str(exact), "--graph", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = _last_json(out)
+    assert r["collective_backend"] == "nccl" and r["rccl_ranks"] == 1 and r["n_gpus"] == 1
+    assert r["exact_mask_normalisation"] == bool(exact)
+    assert r["value"] > 0 and r["train"]["final_loss"] == r["train"]["final_loss"]
+    assert "ddp1" in r["config"]["parallelism"]
+    assert r["warp_loss"]["graph_error"] is None

@@ -186,8 +186,7 @@ def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto, 
     vo, go = run("cpu", O.photo_and_geometry_loss, O.smooth_loss)
     v64, g64 = run("cpu", O.photo_and_geometry_loss, O.smooth_loss, torch.float64)
     for a, b, nm in zip(vh, vo, ("photo", "geom", "smooth")):
-        # the bar is 1e-5 per compute_pairwise_loss term; photo / geom are sums over 2 * n_ref * scales of them
-        assert abs(a - b) <= 1e-5 * max(1, n_ref * scales / 2), (nm, a, b)
+        assert abs(a - b) <= 1e-5, (nm, a, b)  # north_star's bar, flat (photo / geom are sums over 2 * n_ref * scales terms)
     if depth == "iid":  # pose gradients of iid inputs: row statistics (see POSE_RTOL_IID above)
         rel = lambda x, c: (x - c).abs().max(dim=1).values / c.abs().max(dim=1).values
         rows_h = torch.cat([rel(gh[i], g64[i]) for i in range(n_ref + 1, 3 * n_ref + 1)])
@@ -654,3 +653,158 @@ def test_single_node_step_equals_the_three_reference_style_calls(LF, dev):
     for a, b in zip(td + [t for r in rd for t in r] + pp + pi, td2 + [t for r in rd2 for t in r] + pp2 + pi2):
         scale = float(a.grad.abs().max())
         assert float((b.grad - a.grad).abs().max()) <= 2e-5 * scale
+
+
+# ------------------------------------------------------------------------------------------------
+# 7. fp32 product path against fp64, entry by entry, away from the gates
+# ------------------------------------------------------------------------------------------------
+def _unsafe_maps(O, d, n_ref, pad):
+    """Per depth map (target, reference 0 .. n_ref - 1): the entries of its gradient that may depend on which side an
+    fp32 gate fell (oracle.pairwise_gate_margins in fp64), over every pair-direction that touches the map."""
+    c = lambda t: t.double()
+    ti, K = c(d["tgt_img"]), c(d["intrinsics"])
+    unsafe = [torch.zeros(ti.shape[0], ti.shape[2], ti.shape[3], dtype=torch.bool) for _ in range(1 + n_ref)]
+    for i in range(n_ref):
+        ri, td, rd = c(d["ref_imgs"][i]), c(d["tgt_depth"][0]), c(d["ref_depths"][i][0])
+        for (a_img, b_img, a_d, b_d, pose, ia, ib) in ((ti, ri, td, rd, c(d["poses"][i]), 0, 1 + i),
+                                                       (ri, ti, rd, td, c(d["poses_inv"][i]), 1 + i, 0)):
+            m = O.pairwise_gate_margins(a_img, b_img, a_d, b_d, pose, K, 1, 1, 1, pad)
+            dense, scatter = O.unsafe_gradient_entries(m)
+            unsafe[ia] |= dense
+            unsafe[ib] |= scatter
+    return unsafe
+
+
+@pytest.mark.parametrize("B,depth,pad", [(12, "smooth", "zeros"), (4, "iid", "zeros"), (4, "smooth", "border")])
+def test_depth_gradients_entrywise_away_from_the_gates(LF, dev, B, depth, pad):
+    """What the fp64 instantiations cannot reach -- the fp32-only code of the product (LDS aliasing, staged taps, the
+    fixed-point scatter window) -- judged entry by entry at BASELINE size, with NO outlier allowance.
+
+    Every entry of the three depth gradients of compute_photo_and_geometry_loss whose value cannot hinge on a gate
+    decided within fp32 round-off (oracle.pairwise_gate_margins, evaluated in fp64; >= 92 % of the entries) must lie
+    within 0.3 % of the tensor's largest entry of the fp64 oracle's value (5 % on iid inputs) -- the entries set aside
+    are off by up to a third of it, in the reference's own fp32 arithmetic as much as here (measured,
+    tools/diag_gates.py) -- and the error distribution over those entries (median, 99 %, 99.9 %) must be no wider than
+    twice that of the reference's fp32 arithmetic against the same fp64 values.  (fp32 against fp64 cannot be asked
+    for more: sigma = E[x^2] - mu^2 and I[x0 + 1] - I[x0] cancel, and the reference's own fp32 entries sit at a median
+    of 4e-7, a 99.9 % quantile of 3e-5 and a maximum of 5e-4 of the scale.)"""
+    from oracle import scsfm_oracle as O
+    from scsfm_hip import synth
+    H, W, n_ref = 256, 832, 2
+    d = synth.make_batch(B, H, W, n_ref=n_ref, seed=29, depth=depth, image="smooth" if depth == "smooth" else "iid", dataset="kitti")
+    flags = (1, 1, 1, pad)
+
+    def run(device, fn, dtype):
+        mv = lambda t: t.to(device=device, dtype=dtype).clone().requires_grad_(True)
+        cv = lambda t: t.to(device=device, dtype=dtype)
+        td, rd = [mv(d["tgt_depth"][0])], [[mv(r[0])] for r in d["ref_depths"]]
+        ps, pi = [mv(p) for p in d["poses"]], [mv(p) for p in d["poses_inv"]]
+        photo, geom = fn(cv(d["tgt_img"]), [cv(r) for r in d["ref_imgs"]], cv(d["intrinsics"]), td, rd, ps, pi, 1, *flags)
+        (photo + 0.5 * geom).backward()
+        return [float(photo.detach()), float(geom.detach())], [g.grad.detach().cpu().double() for g in td + [r[0] for r in rd]]
+
+    vh, gh = run(dev, LF.compute_photo_and_geometry_loss, torch.float32)
+    v32, g32 = run("cpu", O.photo_and_geometry_loss, torch.float32)
+    v64, g64 = run("cpu", O.photo_and_geometry_loss, torch.float64)
+    assert abs(vh[0] - v64[0]) <= 1e-5 and abs(vh[1] - v64[1]) <= 1e-5, (vh, v64)
+    unsafe = _unsafe_maps(O, d, n_ref, pad)
+    cap = 5e-2 if depth == "iid" else 3e-3
+    for i, (a, o, c, u) in enumerate(zip(gh, g32, g64, unsafe)):
+        a, o, c = a[:, 0], o[:, 0], c[:, 0]
+        keep = ~u
+        share = float(keep.double().mean())
+        scale = float(c.abs().max())
+        eh, eo = ((a - c).abs() / scale)[keep], ((o - c).abs() / scale)[keep]
+        q = lambda t: [float(torch.quantile(t[::3], p)) for p in (0.5, 0.99, 0.999)]
+        qh, qo = q(eh), q(eo)
+        print(f"[{depth}/{pad}] map {i}: judged {share:.4f} of the entries; error / scale: hip median {qh[0]:.2e} p99 {qh[1]:.2e} "
+              f"p99.9 {qh[2]:.2e} max {float(eh.max()):.2e} | reference fp32 {qo[0]:.2e} {qo[1]:.2e} {qo[2]:.2e} max {float(eo.max()):.2e} "
+              f"| set aside: hip max {float(((a - c).abs() / scale)[u].max()):.2e}")
+        assert share >= 0.92, (i, share)
+        assert float(eh.max()) <= cap, (i, float(eh.max()))
+        for x, y in zip(qh, qo):
+            assert x <= 2 * y + 1e-7, (i, qh, qo)
+
+
+def test_other_loss_weights_converge_to_the_speculative_path(LF, dev):
+    """The reference's call structure with -p 1 -c 0.3 and NO set_weight_hint (a drop-in user of the reference's
+    train.py): the first step mis-speculates on the default 1 : 0.5 and runs the backward's own passes; the backward
+    leaves the weights it saw on the device (scsfm_pair_desc::hint), and from the second step on the forward's results
+    stand: the backward is the guards + the combine.  Gradients equal the no-speculation path's in every step."""
+    from scsfm_hip import config, synth
+    d = synth.make_batch(12, 256, 832, n_ref=2, seed=5, depth="smooth", image="smooth", dataset="kitti")
+    to = lambda t: t.to(dev)
+    tgt, K, refs = to(d["tgt_img"]), to(d["intrinsics"]), [to(t) for t in d["ref_imgs"]]
+    w1, w3 = 1.0, 0.3
+
+    def step():
+        mv = lambda t: t.to(dev).clone().requires_grad_(True)
+        td, rd = [mv(d["tgt_depth"][0])], [[mv(r[0])] for r in d["ref_depths"]]
+        ps, pi = [mv(p) for p in d["poses"]], [mv(p) for p in d["poses_inv"]]
+        photo, geom = LF.compute_photo_and_geometry_loss(tgt, refs, K, td, rd, ps, pi, 1, 1, 1, 1, "zeros")
+        loss = w1 * photo + w3 * geom
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        loss.backward()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1), [float(photo.detach()), float(geom.detach())], \
+            [t.grad.clone() for t in td + [r[0] for r in rd] + ps + pi]
+
+    config.set_weight_hint(None, None)
+    try:
+        _, v_ref, g_ref = step()
+    finally:
+        config.set_weight_hint(1.0, 0.5)  # the package default
+    times = []
+    for i in range(4):
+        t, v, g = step()
+        times.append(t)
+        assert abs(v[0] - v_ref[0]) <= 1e-6 and abs(v[1] - v_ref[1]) <= 1e-6, (i, v, v_ref)
+        hint = config.hint_tensor(torch.device(dev)).tolist()
+        assert abs(hint[0] - 1.0) < 1e-12 and abs(hint[1] - float(np.float32(0.3))) < 1e-12, hint
+        for a, b in zip(g, g_ref):
+            scale = float(b.abs().max())
+            if a.dim() == 4:
+                assert_close_frac(a.cpu().numpy(), b.cpu().numpy(), atol=2e-4 * scale, max_bad_frac=1e-3, what=f"step {i}")
+            else:
+                assert float((a - b).abs().max()) <= 1.5e-2 * scale, (i, scale)
+    print("backward ms per step (first mis-speculates):", [round(t, 3) for t in times])
+    # the fall-back costs ~0.65 ms at this size, the guards + combine ~0.03 ms (+ autograd's own kernels)
+    assert min(times[1:]) < 0.5 * times[0], times
+
+
+def test_baseline_size_fixture_recorded_from_the_reference(LF, dev):
+    """tests/golden/cfg1_reference.npz: the unmodified reference (CPU, fp32) at BASELINE.json configs[1] size -- 12 x 256 x
+    832, 2 refs, SSIM + mask + auto-mask -- recorded in the build container (oracle/make_golden.py: gen_cfg1).  Losses to
+    1e-5; every gradient's sum / sum of magnitudes / l2 norm / probe projection; a strided sample of each depth gradient
+    entry-wise; the pose gradients in full."""
+    from scsfm_hip import synth
+    z = load_npz("cfg1_reference.npz")
+    d = synth.make_batch(12, 256, 832, n_ref=2, seed=101, depth="smooth", image="smooth", dataset="kitti")
+    chk = np.array([float(d["tgt_img"].double().sum()), float(d["tgt_depth"][0].double().sum()), float(d["poses"][0].double().sum())])
+    assert np.allclose(chk, z["input_check"], rtol=1e-12, atol=0), "the seeded inputs differ from the recorded ones"
+    to = lambda t: t.to(dev)
+    td, rd = [_leaf(d["tgt_depth"][0], dev)], [[_leaf(r[0], dev)] for r in d["ref_depths"]]
+    ps, pi = [_leaf(p, dev) for p in d["poses"]], [_leaf(p, dev) for p in d["poses_inv"]]
+    tgt, refs, K = to(d["tgt_img"]), [to(r) for r in d["ref_imgs"]], to(d["intrinsics"])
+    photo, geom = LF.compute_photo_and_geometry_loss(tgt, refs, K, td, rd, ps, pi, 1, 1, 1, 1, "zeros")
+    smooth = LF.compute_smooth_loss(td, tgt, rd, refs)
+    (1.0 * photo + 0.1 * smooth + 0.5 * geom).backward()
+    for nm, a in (("photo", photo), ("geom", geom), ("smooth", smooth)):
+        assert abs(float(a) - float(z[nm])) <= 1e-5, (nm, float(a), float(z[nm]))
+    probe = torch.cos(0.37 * torch.arange(12 * 256 * 832, dtype=torch.float64)).float().double()
+    for name, t in [("g_tgt_depth", td[0])] + [(f"g_ref{i}_depth", rd[i][0]) for i in range(2)]:
+        g = t.grad.detach().cpu().double().reshape(-1)
+        s, sa, l2, pr, mx = z[f"{name}/checks"]
+        got = (float(g.sum()), float(g.abs().sum()), float(g.norm()), float((g * probe).sum()))
+        print(f"{name}: sum {got[0]:.6e} (ref {s:.6e})  sum|.| {got[1]:.6e} ({sa:.6e})  l2 {got[2]:.6e} ({l2:.6e})  probe {got[3]:.6e} ({pr:.6e})")
+        # a pixel whose gate rounds the other way moves an entry by up to a third of the scale (SURVEY.md H5): the
+        # checksums are compared at 1e-3 of the sum of magnitudes / of the norm, the sample entry-wise
+        assert abs(got[0] - s) <= 1e-3 * sa and abs(got[1] - sa) <= 1e-3 * sa and abs(got[2] - l2) <= 2e-3 * l2 and abs(got[3] - pr) <= 1e-3 * sa, name
+        assert_close_frac(g[::997].numpy(), z[f"{name}/sample"].astype(np.float64), atol=2e-3 * mx, rtol=1e-3, max_bad_frac=2e-3, what=name)
+    for i in range(2):
+        for nm, t in ((f"g_pose{i}", ps[i]), (f"g_pose_inv{i}", pi[i])):
+            want = z[nm].astype(np.float64)
+            assert float(np.abs(t.grad.cpu().numpy() - want).max()) <= POSE_RTOL * float(np.abs(want).max()), nm

@@ -584,3 +584,58 @@ def test_single_node_step_equals_the_three_reference_style_calls(lib, monkeypatc
     assert abs(float(loss) - float(w1 * photo + w2 * smooth + w3 * geom)) < 1e-13
     for a, b in zip(td + [t for r in rd for t in r] + pp + pi, td2 + [t for r in rd2 for t in r] + pp2 + pi2):
         assert _rel(b.grad, a.grad) < 1e-11
+
+
+def _sums_of(lib, ws, j, B, H, W):
+    """double[16] of pair j's workspace (csrc/scsfm_common.h: PairWs -- the B constants slots of 256 bytes come first)."""
+    ws_bytes, scratch_bytes, _ = capi._sizes(lib, B, H, W)
+    stride = ws_bytes + scratch_bytes
+    off = j * stride + 256 * B
+    return ws[off:off + 128].view(torch.float64)
+
+
+def test_the_device_side_hint_follows_the_upstream_gradients(lib):
+    """scsfm_pair_desc::hint: a training loop with other loss weights than the host hint (here -p 1 -c 0.3 against the
+    default 1 : 0.5) mis-speculates ONCE.  The backward falls back to its own passes, leaves the weights it saw on the
+    device, and from the next step on the forward speculates on them: its results stand (the workspace still carries a
+    valid speculation after the backward) and the gradients equal the oracle's either way."""
+    B, H, W = 4, 72, 100
+    d = synth.make_batch(B, H, W, n_ref=1, seed=41, depth="smooth")
+    c = lambda x: x.double().contiguous()
+    ti, K = c(d["tgt_img"]), c(d["intrinsics"])
+    ris = [c(r) for r in d["ref_imgs"]]
+    tds, rds = [c(d["tgt_depth"][0])], [[c(r[0])] for r in d["ref_depths"]]
+    ps, pis = [c(p) for p in d["poses"]], [c(p) for p in d["poses_inv"]]
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    up = (1.0, 0.3)
+    td, rd = [leaf(t) for t in tds], [[leaf(t) for t in r] for r in rds]
+    pp, pi = [leaf(p) for p in ps], [leaf(p) for p in pis]
+    po, go = O.photo_and_geometry_loss(ti, ris, K, td, rd, pp, pi, 1, 1, 1, 1, "zeros")
+    assert float(go) > 0  # the geometry gate is open: the ratio matters
+    (up[0] * po + up[1] * go).backward()
+    hint_dev = torch.tensor([1.0, 0.5], dtype=torch.float64)
+    t = lambda v: torch.tensor([v], dtype=torch.float64)
+    held = []
+    for step in range(3):
+        photo, geom, _, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=(1.0, 0.5), hint_dev=hint_dev)
+        assert abs(float(photo) - float(po)) < 1e-12 and abs(float(geom) - float(go)) < 1e-12
+        g_td, g_rd, g_p, g_pi = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, t(up[0]), t(up[1]),
+                                                        hint_dev=hint_dev)
+        assert _rel(g_td[0], td[0].grad) < 1e-10 and _rel(g_rd[0][0], rd[0][0].grad) < 1e-10, step
+        assert _rel(g_p[0], pp[0].grad) < 1e-10 and _rel(g_pi[0], pi[0].grad) < 1e-10, step
+        assert hint_dev.tolist() == [1.0, 0.3]
+        # sums[8]: still a valid speculation after the backward (1) or retired by the fallback (0)
+        held.append([float(_sums_of(lib, ws, j, B, H, W)[8]) for j in range(2)])
+    assert held == [[0.0, 0.0], [1.0, 1.0], [1.0, 1.0]], held
+    # a backward with a zero photometric weight: nothing to factor out next time, the forward says so itself
+    photo, geom, _, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=(1.0, 0.5), hint_dev=hint_dev)
+    capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, t(0.0), t(0.7), hint_dev=hint_dev)
+    assert hint_dev.tolist() == [0.0, 0.7]
+    photo, geom, _, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=(1.0, 0.5), hint_dev=hint_dev)
+    assert float(_sums_of(lib, ws, 0, B, H, W)[8]) == 0.0
+    td2, rd2 = [leaf(x) for x in tds], [[leaf(x) for x in r] for r in rds]
+    pp2, pi2 = [leaf(p) for p in ps], [leaf(p) for p in pis]
+    po2, go2 = O.photo_and_geometry_loss(ti, ris, K, td2, rd2, pp2, pi2, 1, 1, 1, 1, "zeros")
+    (0.0 * po2 + 0.7 * go2).backward()
+    g_td, g_rd, g_p, g_pi = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, t(0.0), t(0.7), hint_dev=hint_dev)
+    assert _rel(g_td[0], td2[0].grad) < 1e-10 and _rel(g_p[0], pp2[0].grad) < 1e-10

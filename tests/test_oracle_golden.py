@@ -118,3 +118,33 @@ def test_pose_and_errors():
     for ds in ("kitti", "nyu"):
         out = O.depth_errors(torch.from_numpy(gold[f"errors/{ds}/gt"]), torch.from_numpy(gold[f"errors/{ds}/pred"]), ds)
         np.testing.assert_allclose(out, gold[f"errors/{ds}/out"], rtol=1e-6, atol=1e-7)
+
+
+def test_oracle_reproduces_the_reference_at_baseline_size():
+    """cfg1_reference.npz: the unmodified reference at BASELINE.json configs[1] size (12 x 256 x 832, 2 refs; recorded by
+    oracle/make_golden.py: gen_cfg1).  The oracle in its ATen mode calls the same CPU kernels: losses, gradient
+    checksums and samples agree to fp32 round-off of the sums."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import scsfm_oracle as O
+    from scsfm_hip import synth
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg1_reference.npz"))
+    d = synth.make_batch(12, 256, 832, n_ref=2, seed=101, depth="smooth", image="smooth", dataset="kitti")
+    chk = np.array([float(d["tgt_img"].double().sum()), float(d["tgt_depth"][0].double().sum()), float(d["poses"][0].double().sum())])
+    assert np.allclose(chk, z["input_check"], rtol=1e-12, atol=0), "the seeded inputs differ from the recorded ones"
+    leaf = lambda t: t.clone().requires_grad_(True)
+    td, rd = [leaf(d["tgt_depth"][0])], [[leaf(r[0])] for r in d["ref_depths"]]
+    ps, pi = [leaf(p) for p in d["poses"]], [leaf(p) for p in d["poses_inv"]]
+    photo, geom = O.photo_and_geometry_loss(d["tgt_img"], d["ref_imgs"], d["intrinsics"], td, rd, ps, pi, 1, 1, 1, 1, "zeros", impl="aten")
+    smooth = O.smooth_loss(td, d["tgt_img"], rd, d["ref_imgs"])
+    (1.0 * photo + 0.1 * smooth + 0.5 * geom).backward()
+    assert abs(float(photo) - float(z["photo"])) <= 2e-6 and abs(float(geom) - float(z["geom"])) <= 2e-6
+    assert abs(float(smooth) - float(z["smooth"])) <= 1e-6
+    for name, t in [("g_tgt_depth", td[0])] + [(f"g_ref{i}_depth", rd[i][0]) for i in range(2)]:
+        g = t.grad.double().reshape(-1)
+        want = z[f"{name}/checks"]
+        assert abs(float(g.sum()) - want[0]) <= 1e-5 * want[1] and abs(float(g.abs().sum()) - want[1]) <= 1e-5 * want[1], name
+        assert np.allclose(t.grad.reshape(-1)[::997].numpy(), z[f"{name}/sample"], rtol=1e-3, atol=1e-6 * want[4]), name
+    for i in range(2):
+        assert np.allclose(ps[i].grad.numpy(), z[f"g_pose{i}"], rtol=1e-3, atol=1e-4 * np.abs(z[f"g_pose{i}"]).max())

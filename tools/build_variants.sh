@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 mkdir -p variants
 while [ $# -ge 2 ]; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -munsafe-fp-atomics -fno-gpu-rdc -fno-slp-vectorize \
-    -Wno-unused-function -Iinclude $2 -o variants/$1.so sc-sfmlearner-release_amd/csrc/*.hip &
+    -Wno-unused-function -Iinclude -DSCSFM_WITH_MARCH $2 -o variants/$1.so sc-sfmlearner-release_amd/csrc/*.hip &
   shift 2
 done
 wait
