@@ -140,6 +140,8 @@ def time_kernels(x, flags, iters, n_ref):
     hint = (W_PHOTO, W_GEOM)
     _, _, _, ws_spec = capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, hint=hint)
     _, _, _, ws_plain = capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, hint=None)
+    _, _, _, ws_stale = capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, hint=hint)
+    third = torch.full((1,), 0.3, device=tgt.device)
     frames, imgs = tds + [r[0] for r in rds], [tgt] + list(refs)
     _, sws = capi.smooth_multi_fwd(lib, frames, imgs)
     calls = {
@@ -150,6 +152,11 @@ def time_kernels(x, flags, iters, n_ref):
         "pairs_fwd_plain": lambda: capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, hint=None),
         "pairs_bwd_after_spec": lambda: capi.photo_geometry_bwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, ws_spec, one, half),
         "pairs_bwd_after_plain": lambda: capi.photo_geometry_bwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, ws_plain, one, half),
+        # the first step after the loss weights changed (-p 1 -c 0.3 against a forward that speculated on 1 : 0.5): the
+        # backward's own two passes run once; it leaves the new weights on the device (scsfm_pair_desc::hint) and the
+        # next forward speculates on them, i.e. every later step is `pairs_bwd_after_spec` again
+        "pairs_bwd_first_step_after_weight_change": lambda: capi.photo_geometry_bwd(lib, fl, tgt, K, refs, tds, rds, ps, pis,
+                                                                                    ws_stale, one, third),
         "smooth_fwd": lambda: capi.smooth_multi_fwd(lib, frames, imgs),
         "smooth_bwd": lambda: capi.smooth_multi_bwd(lib, frames, imgs, sws, one),
     }
@@ -262,19 +269,13 @@ def cpu_baseline(args, budget_s):
 
 
 def library_identity(lib):
-    """Which binary served the run: resolved path, ABI version, size + sha256 of the .so and of the sources it was
-    built from (csrc/*, include/scsfm_hip.h)."""
-    import glob
+    """Which binary served the run: resolved path, ABI version, size + sha256 of the .so, the hash of the sources next to
+    it (csrc/*, include/scsfm_hip.h: scsfm_hip.build.source_id) and the one compiled into the binary."""
     import hashlib
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(PKG, "csrc", "*"))) + [os.path.join(ROOT, "include", "scsfm_hip.h")]:
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
-    blob = open(lib.path, "rb").read()
     from scsfm_hip import build as hip_build
-    assert h.hexdigest()[:16] == hip_build.source_id()
+    blob = open(lib.path, "rb").read()
     return {"path": os.path.realpath(lib.path), "abi_version": int(lib._dll.scsfm_abi_version()), "bytes": len(blob),
-            "so_sha256_16": hashlib.sha256(blob).hexdigest()[:16], "source_sha256_16": h.hexdigest()[:16],
+            "so_sha256_16": hashlib.sha256(blob).hexdigest()[:16], "source_sha256_16": hip_build.source_id(),
             # what the binary itself says it was built from (scsfm_source_id): the loader rebuilds or refuses on a mismatch
             "source_id_in_binary": lib.source_id(),
             "env_override": bool(os.environ.get("SCSFM_HIP_LIB"))}
@@ -304,6 +305,10 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="1: also time the hot-path step as a HIP-graph replay (scsfm_hip.graphs.GraphedStep) when "
                          "running on one GPU, 2: also under torchrun, 0: eager launches only")
+    ap.add_argument("--data", default="synthetic", choices=["synthetic", "loader"],
+                    help="loader: ALSO measure the input pipeline on its own (tools/loader_bench.py: JPEG SequenceFolder tree, "
+                         "transform chain in the loader workers vs on the device) and report it as `input_pipeline`; the "
+                         "timed training steps keep their HBM-resident synthetic batch (the contract's `data`)")
     ap.add_argument("--force-dist", default="none", choices=["none", "nccl", "gloo"],
                     help="with one rank: still create a process group of this backend, wrap the nets in "
                          "DistributedDataParallel and run every collective of the multi-GPU path (world size 1)")
@@ -536,6 +541,10 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        if world == 1 and args.data == "loader":
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import loader_bench
+            res["input_pipeline"] = loader_bench.run(args.batch, args.height, args.width, args.n_ref + 1)
         print(json.dumps(res), flush=True)
     if dist_on:
         dist.barrier()

@@ -380,8 +380,11 @@ def pairwise_gate_margins(tgt_img, ref_img, tgt_depth, ref_depth, pose, K, with_
     iy = ((yn + 1) * H - 1) / 2
     if padding_mode == "border":
         hard |= (ix.abs() < eps_px) | ((ix - (W - 1)).abs() < eps_px) | (iy.abs() < eps_px) | ((iy - (H - 1)).abs() < eps_px)
+        # (a clipped coordinate sits exactly on the border and has no gradient: nothing switches there)
+        inside = (ix > 0) & (ix < W - 1) & (iy > 0) & (iy < H - 1)
         ix, iy = ix.clamp(0, W - 1), iy.clamp(0, H - 1)
-    inside = (xn.abs() <= 1) & (yn.abs() <= 1) if padding_mode == "zeros" else torch.ones_like(hard)
+    else:
+        inside = (xn.abs() <= 1) & (yn.abs() <= 1)
     fx, fy = ix - ix.floor(), iy - iy.floor()
     own = inside & ((torch.minimum(fx, 1 - fx) < eps_px) | (torch.minimum(fy, 1 - fy) < eps_px))
     warped, valid, proj_depth, comp_depth = inverse_warp2(ref_img, tgt_depth, ref_depth, pose, K, padding_mode, "explicit")

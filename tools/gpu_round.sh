@@ -10,7 +10,9 @@ O=$R/gpurun_out
 mkdir -p $O
 echo "=== smoke"; python __graft_entry__.py --smoke > $O/smoke_$TAG.log 2>&1; echo "smoke rc=$?"; tail -3 $O/smoke_$TAG.log
 echo "=== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu_$TAG.log
-echo "=== bench"; timeout 900 python bench.py --steps 50 --warmup 10 > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc=$?"; cut -c1-2600 $O/bench_$TAG.json; tail -2 $O/bench_$TAG.err
+echo "=== bench (+ input pipeline leg)"; timeout 1200 python bench.py --steps 50 --warmup 10 --data loader > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc=$?"; cut -c1-2600 $O/bench_$TAG.json; tail -2 $O/bench_$TAG.err
+echo "=== bench over RCCL at world size 1 (process group on nccl, DistributedDataParallel, default and exact mode)"
+for EX in 0 1; do MASTER_PORT=$((29600 + EX)) timeout 600 python bench.py --steps 10 --warmup 3 --loss-steps 10 --loss-warmup 3 --cpu-seconds 0 --force-dist nccl --exact $EX --graph 2 > $O/bench_${TAG}_rccl1_exact$EX.json 2>> $O/bench_$TAG.err; cut -c1-700 $O/bench_${TAG}_rccl1_exact$EX.json; done
 echo "=== bench iid"; timeout 600 python bench.py --loss-steps 30 --loss-warmup 5 --depth iid --cpu-seconds 0 --e2e 0 > $O/bench_${TAG}_iid.json 2>> $O/bench_$TAG.err; cut -c1-400 $O/bench_${TAG}_iid.json
 echo "=== bench configs[3] (ResNet50 encoder, batch 8 per GPU) and configs[4] (NYU 256x320, sequence length 5, batch 16): whole training step + loss path"
 timeout 900 python bench.py --steps 10 --warmup 3 --resnet-layers 50 --batch 8 --loss-steps 30 --loss-warmup 5 --cpu-seconds 0 > $O/bench_${TAG}_cfg3.json 2>> $O/bench_$TAG.err; cut -c1-420 $O/bench_${TAG}_cfg3.json
@@ -23,3 +25,9 @@ done
 cd $R
 python tools/rocprof_summary.py $O/prof_$TAG/trace_results.db | grep -v "at::native\|rocclr" | head -20
 bash tools/gpu_sq.sh $TAG > $O/sq_$TAG.txt 2>&1; tail -14 $O/sq_$TAG.txt
+echo "=== stage timeline of the tile kernel (PROBE_TIMING build) and the column-march variant for the record"
+if [ -f variants/t4time.so ]; then SCSFM_HIP_LIB=$R/variants/t4time.so timeout 300 python tools/march_timing.py 2>&1 | tail -n 1 | tee $O/timing_${TAG}_tile.json; fi
+if [ -f variants/m3.so ]; then
+  SCSFM_HIP_LIB=$R/variants/m3.so timeout 300 python tools/march_sweep.py --rows 64 2>&1 | tail -n 1 | tee $O/sweep_${TAG}_tile.json
+  SCSFM_SPEC_KERNEL=march SCSFM_HIP_LIB=$R/variants/m3.so timeout 300 python tools/march_sweep.py --rows 32,64,128 2>&1 | tail -n 1 | tee $O/sweep_${TAG}_march.json
+fi
