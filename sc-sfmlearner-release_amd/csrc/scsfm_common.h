@@ -148,6 +148,24 @@ __device__ __forceinline__ void block_sum(T (&v)[N], double* scratch) {
   }
 }
 
+// The same sums, stored: out[i] (fp64) = sum over the block of v[i].  After the waves' packed sums meet in `scratch`, lane i
+// of the first wave adds up value i and writes it -- N threads with kThreads / kWave additions each instead of one
+// thread with N of them (the fp64 additions of a serial tail sat on wave 0 of every workgroup: 60 for N = 12).
+template <int N, typename T>
+__device__ __forceinline__ void block_sum_store(T (&v)[N], double* scratch, double* __restrict__ out) {
+  const int wave = threadIdx.x / kWave;
+  bool lead;
+  const int idx = wave_sum_packed<N>(v, lead);
+  if (lead) scratch[wave * N + idx] = double(v[0]);
+  __syncthreads();
+  if (threadIdx.x < N) {
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / kWave; ++w) s += scratch[w * N + threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+}
+
 // XCD-aware block order.  The dispatcher hands consecutive workgroups to the 8 XCDs round-robin (observed,
 // not contractual: used for speed only), so with the natural order horizontally adjacent tiles -- which
 // share ring pixels and gather from the same neighbourhood -- sit on different, mutually non-coherent L2s.

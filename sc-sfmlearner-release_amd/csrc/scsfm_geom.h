@@ -145,9 +145,12 @@ __global__ void pose_bwd_kernel(int B, const T* __restrict__ pose, const T* __re
 // One wave per batch element: ordered fp64 reduction of the per-block partials gPp[b][nblk][12]
 // written by pair_bwd_geom_kernel, then the pose chain.  `live` = the geometry pass ran (it skips
 // when both upstream coefficients are zero and then leaves the partials untouched).
+template <typename T> struct BatchConsts;
+template <typename T, typename A> __device__ __forceinline__ void pose_partials_to_A(const BatchConsts<T>& bc, A* acc);
 template <typename T>
 __device__ __forceinline__ void pose_reduce_one(int b, int nblk, double scale, const T* __restrict__ pose,
-                                                const T* __restrict__ K, const double* __restrict__ gPp,
+                                                const T* __restrict__ K, const BatchConsts<T>* __restrict__ consts,
+                                                const double* __restrict__ gPp,
                                                 const double* __restrict__ sums, const T* __restrict__ g_photo,
                                                 const T* __restrict__ g_geom, T* __restrict__ gpose) {
   const int lane = threadIdx.x & (kWave - 1);  // one wave per call (of a 64-thread or a larger workgroup)
@@ -164,7 +167,11 @@ __device__ __forceinline__ void pose_reduce_one(int b, int nblk, double scale, c
 #pragma unroll
     for (int i = 0; i < 12; ++i) g[i] = wave_sum(g[i]) * scale;
   }
-  if (lane == 0) pose_from_gP(K + 9 * b, pose + 6 * b, g, gpose + 6 * b);
+  if (lane == 0) {
+    // the partials are sums against the pixel-frame point depth * (u, v, 1): dL/dA = G K^-T, once per image
+    pose_partials_to_A(consts[b], g);
+    pose_from_gP(K + 9 * b, pose + 6 * b, g, gpose + 6 * b);
+  }
 }
 
 // ------------------------------------------------------------------------------------------

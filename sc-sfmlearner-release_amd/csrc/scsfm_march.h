@@ -445,7 +445,6 @@ __device__ __forceinline__ void march_segment(const BlockId blk, int nbands, int
       g[i] = 0.0;
       for (int w = 0; w < NW; ++w) g[i] += sAcc[w][i];
     }
-    pose_partials_to_A(pa.consts[b], g);
 #pragma unroll
     for (int i = 0; i < 12; ++i) o[i] = g[i];
   }

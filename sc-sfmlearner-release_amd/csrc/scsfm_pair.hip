@@ -136,7 +136,9 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(PairBatch<T> pb, int
   __shared__ V2 sXY[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];  // (target, warped) + 1-pixel ring
   __shared__ double red[3 * (kThreads / kWave)];
 
-  const int col = threadIdx.x & (kWave - 1), strip = threadIdx.x / kWave;
+  // (the wave index as a scalar for row arithmetic and as a vector register for LDS addresses: scsfm_spec_tile.h)
+  const int col = threadIdx.x & (kWave - 1), strip = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / kWave);
+  const int lrow = (int(threadIdx.x) / kWave) * STRIP;
   const int tx0 = blk.x * kTileW, ty0 = blk.y * TH;
   const bool with_mask = (flags & SCSFM_WITH_MASK) != 0, with_auto = (flags & SCSFM_WITH_AUTO_MASK) != 0;
   const BatchConsts<T> bc = consts[b];
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(PairBatch<T> pb, int
     const Sample<T> s = warp_colours(bc, u, v, in_d[k], in_t[k], H, W, flags, ref_img, xy);
     if (kSsim) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) sXY[c][ly + 1][col + 1] = xy[c];
+      for (int c = 0; c < 3; ++c) sXY[c][lrow + k + 1][col + 1] = xy[c];
     }
     l1sum[k] = clamp01(t_abs(xy[0][0] - xy[0][1])) + clamp01(t_abs(xy[1][0] - xy[1][1])) +
                clamp01(t_abs(xy[2][0] - xy[2][1]));  // loss_functions.py:99, summed over colours
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(PairBatch<T> pb, int
     for (int c = 0; c < 3; ++c) {
       WinSums<T> ws[STRIP];
       V2 centre[STRIP];
-      strip_window_sums<T, STRIP>(sXY[c], strip * STRIP, col, ws, centre);
+      strip_window_sums<T, STRIP>(sXY[c], lrow, col, ws, centre);
 #pragma unroll
       for (int k = 0; k < STRIP; ++k) photo[k] += T(0.85) * clamp01(ssim_stats(ws[k]).raw);
     }
@@ -611,12 +613,8 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
   block_sum<12>(acc, red);
   if (threadIdx.x == 0) {
     double* o = gP + 12 * ((size_t)(b * nby + blk.y) * nbx + blk.x);
-    double g[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) g[i] = double(acc[i]);
-    pose_partials_to_A(bc, g);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) o[i] = g[i];
+    for (int i = 0; i < 12; ++i) o[i] = double(acc[i]);  // (raw: the pose reducer applies K^-1)
   }
 }
 
@@ -673,8 +671,8 @@ __global__ void pairs_pose_reduce_kernel(PairBatch<T> pb, int B, int nblk_geom, 
   if (hint && blockIdx.x == 0 && threadIdx.x == 0) { hint[0] = double(g_photo[0]); hint[1] = double(g_geom[0]); }
   const PairArgs<T>& pa = pb.p[pair];
   const bool spec = spec_valid(pa.sums, g_photo, g_geom);
-  pose_reduce_one(b, spec ? int(pa.sums[11]) : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K, pa.gPp,
-                  pa.sums, g_photo, g_geom, pa.g_pose);
+  pose_reduce_one(b, spec ? int(pa.sums[11]) : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K, pa.consts,
+                  pa.gPp, pa.sums, g_photo, g_geom, pa.g_pose);
   if (b == 0 && threadIdx.x == 0) retire_speculation(pa.sums, g_photo, g_geom);
 }
 
@@ -739,7 +737,7 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
       const PairArgs<T>& pa = pb.p[pair];
       const bool spec = spec_valid(pa.sums, g_photo, g_geom);
       pose_reduce_one(b, spec ? int(pa.sums[11]) : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K,
-                      pa.gPp, pa.sums, g_photo, g_geom, pa.g_pose);
+                      pa.consts, pa.gPp, pa.sums, g_photo, g_geom, pa.g_pose);
       if (b == 0 && (threadIdx.x & (kWave - 1)) == 0) retire_speculation(pa.sums, g_photo, g_geom);
     }
     return;

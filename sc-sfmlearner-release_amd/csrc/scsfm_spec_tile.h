@@ -224,6 +224,39 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
   T stage_v[kStage ? 4 : 1][kStage ? NR + 1 : 1];
   const int er = threadIdx.x / XW, ec = kWave + threadIdx.x - er * XW;  // the columns beyond 64: (row, column) of this thread
   if constexpr (kSpec && kSsim) scatter_box();
+  // The staging loads of the tail (used below).  SCSFM_STAGE_EARLY issues them before the last colour's transposed box
+  // filter, so that their round trip (~3,300 cycles of a tile's 47,000 by the stage timeline) runs under that phase
+  // instead of in front of the tail; the price is their ~20 registers across it.  (A macro, not a lambda: capturing
+  // the staging arrays by reference kept them in scratch memory.)
+#ifndef SCSFM_STAGE_EARLY
+#define SCSFM_STAGE_EARLY 0
+#endif
+#define SCSFM_ISSUE_STAGE_LOADS() \
+  do { \
+      const int bx = wx0 + cx0, by = wy0 + cy0, ex = cx1 - cx0 + 1, ey = cy1 - cy0 + 1; \
+      int sx0 = bx - (kStageW - ex) / 2, sy0 = by - (kStageRows - ey) / 2; \
+      sx0 = sx0 > W - kStageW ? W - kStageW : sx0; sx0 = sx0 < 0 ? 0 : sx0; \
+      sy0 = sy0 > H - kStageRows ? H - kStageRows : sy0; sy0 = sy0 < 0 ? 0 : sy0; \
+      staged.x0 = sx0; staged.y0 = sy0; \
+      staged.colour = sp_colour; staged.depth = sp_depth; staged.stride = kTileFloats; \
+      const int gx = sx0 + col < W ? sx0 + col : W - 1; \
+      const int egx = sx0 + ec < W ? sx0 + ec : W - 1, egy = sy0 + er < H ? sy0 + er : H - 1; \
+  _Pragma("unroll") \
+      for (int i = 0; i <= NR; ++i) { \
+        const int r = strip + i * (kThreads / kWave); \
+        const int gy = sy0 + r < H ? sy0 + r : H - 1; \
+        const int x = i < NR ? gx : egx, y = i < NR ? gy : egy; \
+        const unsigned off = (unsigned(y) * unsigned(W) + unsigned(x)) * unsigned(sizeof(T)); \
+        const bool on = i < NR ? r < kStageRows : threadIdx.x < XW * kStageRows; \
+  _Pragma("unroll") \
+        for (int c = 0; c < 4; ++c) stage_v[c][i] = T(0); \
+        if (on) { \
+  _Pragma("unroll") \
+          for (int c = 0; c < 3; ++c) stage_v[c][i] = ld_at(ref_img + c * plane, off); \
+          if (!kLean) stage_v[3][i] = ref_depth.at(x, y, off); \
+        } \
+      } \
+  } while (0)
   // ---- phases 2/3, one colour channel at a time ------------------------------------------------
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -244,6 +277,9 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
         sG[0][lrow + k][col] = g1; sG[1][lrow + k][col] = g2; sG[2][lrow + k][col] = g3;
       }
       __syncthreads();
+      if constexpr (kStage && SCSFM_STAGE_EARLY == 1) {
+        if (c == 2) SCSFM_ISSUE_STAGE_LOADS();
+      }
       // phase 3: transpose of (reflect-pad + 3x3 box) as a separable 3x3 gather
       T gt[STRIP][3];
       strip_box_transpose<T, STRIP, TH, 3>(sG, lrow, col, px, py0, H, W, gt);
@@ -293,6 +329,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
       }
     }
   } else {
+    if constexpr (kStage && SCSFM_STAGE_EARLY == 2) SCSFM_ISSUE_STAGE_LOADS();  // (in flight under the block sum below)
     // ---- the forward's three sums over the pixels this block owns ---------------------------------
     T v[3] = {T(0), acc_g, acc_m};
 #pragma unroll
@@ -302,11 +339,8 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
       if (in_x && ly >= 1 && ly <= TH - 2 && py < H) v[0] += bsum[k] * coef[k];
     }
     STAMP(4);
-    block_sum<3>(v, red);  // (contains a barrier: the window's zeroes are visible below even without SSIM)
-    if (threadIdx.x == 0) {
-      double* o = partials + 3 * ((size_t)(b * nby + blk.y) * nbx + blk.x);
-      o[0] = double(v[0]); o[1] = double(v[1]); o[2] = double(v[2]);
-    }
+    // (contains a barrier: the window's zeroes are visible below even without SSIM)
+    block_sum_store<3>(v, red, partials + 3 * ((size_t)(b * nby + blk.y) * nbx + blk.x));
     STAMP(5);
     // ---- geometry tail: pass B for the owned pixels, up to the factor the reduction will supply ----
     // (everything downstream of dL/d(warped colour), dL/d diff_depth is linear in them: the dense plane, the
@@ -314,33 +348,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     T* __restrict__ g_dense = pa.gbuf + kPlaneDense * gplane + (size_t)b * plane;
     T* __restrict__ g_scatter = pa.gbuf + kPlaneScatter * gplane + (size_t)b * plane;
     if constexpr (!kSsim) scatter_box();  // (with SSIM: done after the warp phase's barrier)
-    if constexpr (kStage) {
-      // around the taps' bounding box (cells cx0..cx1 x cy0..cy1 of the scatter window), inside the image
-      const int bx = wx0 + cx0, by = wy0 + cy0, ex = cx1 - cx0 + 1, ey = cy1 - cy0 + 1;
-      int sx0 = bx - (kStageW - ex) / 2, sy0 = by - (kStageRows - ey) / 2;
-      sx0 = sx0 > W - kStageW ? W - kStageW : sx0; sx0 = sx0 < 0 ? 0 : sx0;
-      sy0 = sy0 > H - kStageRows ? H - kStageRows : sy0; sy0 = sy0 < 0 ? 0 : sy0;
-      staged.x0 = sx0; staged.y0 = sy0;
-      staged.colour = sp_colour; staged.depth = sp_depth; staged.stride = kTileFloats;
-      // rows by wave, 64 columns by lane; the last kStageW - 64 columns by the first threads
-      const int gx = sx0 + col < W ? sx0 + col : W - 1;
-      const int egx = sx0 + ec < W ? sx0 + ec : W - 1, egy = sy0 + er < H ? sy0 + er : H - 1;
-  #pragma unroll
-      for (int i = 0; i <= NR; ++i) {
-        const int r = strip + i * (kThreads / kWave);
-        const int gy = sy0 + r < H ? sy0 + r : H - 1;
-        const int x = i < NR ? gx : egx, y = i < NR ? gy : egy;
-        const unsigned off = (unsigned(y) * unsigned(W) + unsigned(x)) * unsigned(sizeof(T));
-        const bool on = i < NR ? r < kStageRows : threadIdx.x < XW * kStageRows;
-  #pragma unroll
-        for (int c = 0; c < 4; ++c) stage_v[c][i] = T(0);
-        if (on) {
-  #pragma unroll
-          for (int c = 0; c < 3; ++c) stage_v[c][i] = ld_at(ref_img + c * plane, off);
-          if (!kLean) stage_v[3][i] = ref_depth.at(x, y, off);
-        }
-      }
-    }
+    if constexpr (kStage && !SCSFM_STAGE_EARLY) SCSFM_ISSUE_STAGE_LOADS();
     T d_own[STRIP];  // depth of the owned pixels: kept since phase 0, or (kLean: 4 registers less across the SSIM phases) re-read
 #pragma unroll
     for (int k = 0; k < STRIP; ++k) {
@@ -394,16 +402,10 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     // global memory comes after the last barrier: the round trips of the dense stores and of the window's
     // atomics then overlap with the next workgroup instead of stalling this one.
     STAMP(7);
-    block_sum<12>(acc, red + 3 * (kThreads / kWave));  // (its barrier also orders the scatter's LDS atomics before the flush)
-    if (threadIdx.x == 0) {
-      double* o = pa.gPp + 12 * ((size_t)(b * nby + blk.y) * nbx + blk.x);
-      double g[12];
-#pragma unroll
-      for (int i = 0; i < 12; ++i) g[i] = double(acc[i]);
-      pose_partials_to_A(bc, g);
-#pragma unroll
-      for (int i = 0; i < 12; ++i) o[i] = g[i];
-    }
+    // (its barrier also orders the scatter's LDS atomics before the flush.  Raw sums against the pixel-frame point:
+    // the pose reducer applies K^-1 once per image -- pose_partials_to_A is linear -- instead of wave 0 of every tile
+    // doing 36 fp64 multiply-adds)
+    block_sum_store<12>(acc, red + 3 * (kThreads / kWave), pa.gPp + 12 * ((size_t)(b * nby + blk.y) * nbx + blk.x));
 #pragma unroll
     for (int k = 0; k < STRIP; ++k) {
       const int ly = strip * STRIP + k, py = py0 + k;
@@ -417,4 +419,5 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
 }
 
 
+#undef SCSFM_ISSUE_STAGE_LOADS
 }  // namespace scsfm
