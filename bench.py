@@ -479,6 +479,12 @@ def main():
     roofline = {"bound": "hbm", "kernel": f"{DOMINANT_KERNEL} ({n_pairs} pair-directions per launch)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, n_pairs),
+                # (HBM bytes per launch = FETCH_SIZE + WRITE_SIZE of separate `rocprofv3 --pmc` passes of this command,
+                # QUOTED from the committed profiles/pmc_latest.json -- counters cannot be read inside a timed run)
+                "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_round.sh)",
+                # of the 48 B/px booked on this kernel 8 B/px (the read-modify-write of the gradient maps) are paid by
+                # pairs_combine_kernel: the kernel's own algorithmic bytes are 40 B/px
+                "kernel_own_algorithmic_bytes_per_launch": int(spec_bytes / 48 * 40),
                 "algorithmic_bytes_per_launch": spec_bytes, "avg_launch_us": round(launch_s * 1e6, 2),
                 "launches_timed": in_step_us[2], "min_launch_us": round(in_step_us[1], 2),
                 "back_to_back_launch_us": round(kt["spec_kernel_only"] * 1e6, 2)}

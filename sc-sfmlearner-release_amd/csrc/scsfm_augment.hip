@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kThreads) void augment_kernel(int T, int H, int W, 
   const int v0 = vt[8 * y0], v1 = vt[8 * yl] + vt[8 * yl + 1];
   const int h0 = ht[8 * x0], h1 = ht[8 * xl] + ht[8 * xl + 1];
   // in frame coordinates a flipped tile reads columns W - h1 .. W - 1 - h0
-  const int c0 = flip ? W - h1 : h0, ncols = h1 - h0, nrows = v1 - v0;
+  const int c0 = flip ? W - h1 : h0, nrows = v1 - v0;  // (columns: h1 - h0 <= 64 + 5)
   const uint8_t* __restrict__ src = frames + (size_t)f * H * W * 3;
   // ---- 1. window -> LDS (dwords from the 4-byte aligned address at or before the window's first byte of each row)
   const uint8_t* const buf_end = frames + (size_t)gridDim.z * H * W * 3;

@@ -518,7 +518,9 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
 // forward's results stand (the usual case) every tile returns at once and the launch costs ~1 us instead of
 // the ~12 us of ten thousand empty workgroups.
 template <typename T, bool kSsim, bool kScaled>
-__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) void pair_bwd_photo_kernel(
+// (three workgroups per CU: at four the tile code of this pass spilled six registers -- it only ever runs on the first
+// step after the loss weights changed)
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 3 : 1) void pair_bwd_photo_kernel(
     PairBatch<T> pb, int nbx, int nby, int nz, int B, int H, int W, unsigned flags, const T* __restrict__ g_photo,
     const T* __restrict__ g_geom) {
   const unsigned live = pairs_to_run(pb, nz / B, g_photo, g_geom);

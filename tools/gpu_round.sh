@@ -22,6 +22,10 @@ echo "=== rocprof kernel trace"; timeout 600 rocprofv3 --kernel-trace --stats -d
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "=== rocprof pmc $C"; timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/prof_$TAG -o pmc_$C -- python $R/bench.py --loss-steps 3 --loss-warmup 1 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 2 > $O/rocprof_${TAG}_$C.log 2>&1; echo "rc=$?"
 done
+echo "=== rocprof pmc, iid depth"
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/prof_$TAG -o pmc_iid_$C -- python $R/bench.py --loss-steps 3 --loss-warmup 1 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 2 --depth iid > $O/rocprof_${TAG}_iid_$C.log 2>&1; echo "rc=$?"
+done
 cd $R
 python tools/rocprof_summary.py $O/prof_$TAG/trace_results.db | grep -v "at::native\|rocclr" | head -20
 bash tools/gpu_sq.sh $TAG > $O/sq_$TAG.txt 2>&1; tail -14 $O/sq_$TAG.txt

@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
 """Per-kernel FETCH_SIZE / WRITE_SIZE (KiB per dispatch) from rocprofv3 --pmc runs (rocpd databases).
-    python tools/pmc_summary.py gpurun_out/prof_TAG   ->  text;  --json FILE also writes a machine-readable summary"""
+    python tools/pmc_summary.py gpurun_out/prof_TAG   ->  text;  --json FILE also writes a machine-readable summary;
+    --prefix pmc_iid_ reads the passes of another workload (tools/gpu_round.sh: iid depth)"""
 import json
 import os
 import sqlite3
 import sys
 
 
-def main(d, json_out=None):
+def main(d, json_out=None, prefix="pmc_"):
     res = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = os.path.join(d, f"pmc_{c}_results.db")
+        path = os.path.join(d, f"{prefix}{c}_results.db")
         if not os.path.exists(path):
             continue
         cur = sqlite3.connect(path).cursor()
@@ -34,4 +35,10 @@ def main(d, json_out=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[3] if len(sys.argv) > 3 and sys.argv[2] == "--json" else None)
+    a = sys.argv[1:]
+    pre = "pmc_"
+    if "--prefix" in a:
+        i = a.index("--prefix")
+        pre = a[i + 1]
+        del a[i:i + 2]
+    main(a[0], a[2] if len(a) > 2 and a[1] == "--json" else None, pre)
