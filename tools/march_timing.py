@@ -47,6 +47,9 @@ def main():
     rc = fn(buf.ctypes.data, buf.size)
     assert rc == 0, rc
     t = buf.reshape(NWG, NC, NS).astype(np.int64)
+    if os.environ.get("SCSFM_SPEC_KERNEL", "")[:1] == "m":
+        sys.exit("the column march's stamps were taken out with its per-colour rewrite; the timelines in "
+                 "profiles/r03_march_experiments.json were recorded at commits 1caf5b2 .. fd08494")
     if os.environ.get("SCSFM_SPEC_KERNEL", "")[:1] != "m":  # the tile kernel: every third tile stamps 9 times
         names = ["loads+warp", "ring warp", "barrier", "3 x (S, O)", "block sum", "stage taps", "tail", "block sum 12", "flush"]
         m = t[:, 0, 8] > 0
