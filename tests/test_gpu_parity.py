@@ -790,6 +790,7 @@ def test_other_loss_weights_converge_to_the_speculative_path(LF, dev):
         stride = ws_bytes + scratch_bytes
         held.append([float(ws[j * stride + 256 * 12 + 64:j * stride + 256 * 12 + 72].view(torch.float64)) for j in range(4)])
     assert held == [[0.0] * 4, [1.0] * 4, [1.0] * 4], held
+    config.set_weight_hint(1.0, 0.5)  # (the package default again, on the host and in the device copy)
 
 
 def test_baseline_size_fixture_recorded_from_the_reference(LF, dev):
