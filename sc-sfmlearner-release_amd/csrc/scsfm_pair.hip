@@ -347,12 +347,13 @@ constexpr unsigned kTrainFlags = SCSFM_WITH_SSIM | SCSFM_WITH_MASK | SCSFM_WITH_
 namespace scsfm {
 
 // The speculative forward: one tile per workgroup, XCD-aware order.
-template <typename T, bool kSsim, unsigned kFlags = kRuntimeFlags, bool kScaled = false>
+// (kStageFwd: the forward warp's taps staged in LDS as well -- scsfm_spec_tile.h; tuning / test builds instantiate both)
+template <typename T, bool kSsim, unsigned kFlags = kRuntimeFlags, bool kScaled = false, bool kStageFwd = (SCSFM_STAGE_FWD != 0)>
 __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) void pair_fwd_spec_kernel(PairBatch<T> pb, int B, int H, int W,
                                                                                   unsigned flags, T r_hint,
                                                                                   const double* __restrict__ hint) {
   if (hint) r_hint = hint[0] != 0.0 ? T(3.0 * hint[1] / hint[0]) : T(0);  // (scsfm_pair_desc::hint: the device's pair wins)
-  spec_tile<T, kSsim, kScaled, kFlags>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, pb, B, H, W, flags, nullptr, nullptr, r_hint);
+  spec_tile<T, kSsim, kScaled, kFlags, kStageFwd>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, pb, B, H, W, flags, nullptr, nullptr, r_hint);
 }
 #ifdef SCSFM_WITH_MARCH
 #ifndef SCSFM_MARCH_WAVES_PER_SIMD  // waves per SIMD the march is compiled for (168 VGPRs at 3: no spills; 128 at 4: spills)
@@ -888,12 +889,21 @@ static unsigned debug_extra_lds() {
   }();
   return bytes;
 }
-// Which kernel serves the speculative forward: the tile kernel, or -- in builds that carry it -- the column march
-// (SCSFM_SPEC_KERNEL=march, for A/B measurements; read per launch).
+// Which kernel serves the speculative forward: the tile kernel, or -- in builds that carry them -- the column march
+// (SCSFM_SPEC_KERNEL=march) or the tile kernel with LDS-staged forward taps (SCSFM_SPEC_KERNEL=stagefwd); for A/B
+// measurements and the CPU simulation, read per launch.
 static bool spec_uses_march() {
 #ifdef SCSFM_WITH_MARCH
   const char* e = getenv("SCSFM_SPEC_KERNEL");
   return e && e[0] == 'm';
+#else
+  return false;
+#endif
+}
+static bool spec_stages_fwd() {
+#ifdef SCSFM_WITH_MARCH
+  const char* e = getenv("SCSFM_SPEC_KERNEL");
+  return e && e[0] == 's';
 #else
   return false;
 #endif
@@ -940,6 +950,10 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
                      flags & ~SCSFM_DEBUG_KERNEL_ONLY, r_hint, hint)
       if (!full_res && (flags & SCSFM_WITH_SSIM)) SCSFM_LAUNCH_SPEC(true, kRuntimeFlags, true);
       else if (!full_res) SCSFM_LAUNCH_SPEC(false, kRuntimeFlags, true);
+#ifdef SCSFM_WITH_MARCH
+      else if (spec_stages_fwd() && sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags) SCSFM_LAUNCH_SPEC(true, kTrainFlags, false, true);
+      else if (spec_stages_fwd() && (flags & SCSFM_WITH_SSIM)) SCSFM_LAUNCH_SPEC(true, kRuntimeFlags, false, true);
+#endif
       else if (sizeof(T) == 4 && (flags & ~SCSFM_DEBUG_KERNEL_ONLY) == kTrainFlags) SCSFM_LAUNCH_SPEC(true, kTrainFlags);
       else if (flags & SCSFM_WITH_SSIM) SCSFM_LAUNCH_SPEC(true);
       else SCSFM_LAUNCH_SPEC(false);
