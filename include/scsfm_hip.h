@@ -61,7 +61,8 @@ extern "C" {
  * buffers (2: the batched backwards store their depth gradients; scratch holds six planes.  3: scsfm_smooth_multi_bwd
  * takes `accumulate`; scsfm_step_total / scsfm_step_weights; scsfm_pair_desc::total.  4: scsfm_pixel2cam_*, scsfm_cam2pixel_*,
  * SCSFM_ROT_QUAT_FLAG for the warp entry points.  5: scsfm_pair_desc::depth_shift.  6: scsfm_pair_desc::hint,
- * scsfm_source_id). */
+ * scsfm_source_id.  7: gradients of the data inputs -- scsfm_pair_desc::g_tgt_img / g_ref_img, scsfm_pairs_bwd_inputs,
+ * scsfm_warp_bwd_inputs, scsfm_pixel2cam_bwd_intrinsics, scsfm_masked_mean_bwd_mask, scsfm_smooth_multi_bwd_images). */
 int scsfm_abi_version(void);
 /* Identity of the sources this binary was built from: the first 16 hex digits of the sha256 over csrc/ and this header
  * (scsfm_hip/build.py: source_id(); "unknown" for a build that did not record it), NUL-terminated into buf[n]. */
@@ -168,6 +169,8 @@ typedef struct scsfm_pair_desc {
                       a coarser scale, [B,1,H>>s,W>>s] with H, W multiples of 2^s, and the kernels read them through
                       the index map of F.interpolate(..., (H, W), mode='nearest') (loss_functions.py:77-82) instead of a
                       materialised up-sampled copy; g_tgt_depth / g_ref_depth receive the sum-pooled gradients */
+  void* g_tgt_img; /* read by scsfm_pairs_bwd_inputs only; NULL or [B,3,H,W], ACCUMULATE (atomic adds): dL/d tgt_img of this */
+  void* g_ref_img; /* pair-direction, dL/d ref_img likewise -- zero the buffers before the first call that names them */
 } scsfm_pair_desc;
 
 int scsfm_pairs_fwd_f32(int n, const scsfm_pair_desc* d, int B, int H, int W, const float* intrinsics,
@@ -180,6 +183,20 @@ int scsfm_pairs_fwd_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, co
 int scsfm_pairs_bwd_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, const double* intrinsics,
                         unsigned flags, void* scratch, const double* g_photo, const double* g_geom,
                         void* stream);
+
+/* Gradients of the DATA inputs of the pair losses.  The reference's autograd reaches the images (the target image
+ * through the L1 and SSIM terms, loss_functions.py:99-108; the reference image through grid_sample's input,
+ * inverse_warp.py:262) and the intrinsics (K^-1 of pixel2cam and K [R|t], inverse_warp.py:253-260) although train.py
+ * never asks for them.  Call AFTER scsfm_pairs_bwd with the same descriptors, flags and upstream gradients (the pose
+ * partials the backward left in each `ws` are read again): every non-NULL d[i].g_tgt_img / g_ref_img is ACCUMULATED
+ * into (one extra tiled pass over the pairs that name one); g_intrinsics (NULL or [B,3,3]) is STORED = the sum over
+ * all n pair-directions. */
+int scsfm_pairs_bwd_inputs_f32(int n, const scsfm_pair_desc* d, int B, int H, int W, const float* intrinsics,
+                               unsigned flags, const float* g_photo, const float* g_geom, float* g_intrinsics,
+                               void* stream);
+int scsfm_pairs_bwd_inputs_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, const double* intrinsics,
+                               unsigned flags, const double* g_photo, const double* g_geom, double* g_intrinsics,
+                               void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * inverse_warp2 (inverse_warp.py:230-269) as maps: projected_img [B,3,H,W], valid_mask [B,1,H,W]
@@ -208,11 +225,21 @@ int scsfm_warp_bwd_f64(int B, int H, int W, const double* img, const double* dep
                        unsigned flags, void* ws, const double* g_projected_img,
                        const double* g_projected_depth, const double* g_computed_depth,
                        double* g_depth, double* g_ref_depth, double* g_pose, void* stream);
+/* ... and of its data inputs, AFTER scsfm_warp_bwd on the same `ws` (which keeps the sums of dL/d(K [R|t])):
+ * g_img (NULL or [B,3,H,W], ACCUMULATE: the bilinear splat of g_projected_img, grid_sampler_2d_backward on its input)
+ * and g_intrinsics (NULL or [B,3,3], STORE). */
+int scsfm_warp_bwd_inputs_f32(int B, int H, int W, const float* depth, const float* pose, const float* intrinsics,
+                              unsigned flags, void* ws, const float* g_projected_img, float* g_img,
+                              float* g_intrinsics, void* stream);
+int scsfm_warp_bwd_inputs_f64(int B, int H, int W, const double* depth, const double* pose, const double* intrinsics,
+                              unsigned flags, void* ws, const double* g_projected_img, double* g_img,
+                              double* g_intrinsics, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * pixel2cam (inverse_warp.py:29-44): depth [B,H,W], intrinsics_inv [B,3,3] -> cam [B,3,H,W] (store) =
- * K^-1 (u, v, 1) * depth.  Backward: g_cam [B,3,H,W] -> g_depth [B,H,W] (store).  (No gradient with respect to
- * intrinsics_inv: intrinsics are data on this path.)
+ * K^-1 (u, v, 1) * depth.  Backward: g_cam [B,3,H,W] -> g_depth [B,H,W] (store); the gradient with respect to
+ * intrinsics_inv has its own entry point (scsfm_pixel2cam_bwd_intrinsics: a caller that treats intrinsics as data
+ * never pays for it).
  * cam2pixel (inverse_warp.py:47-74) and cam2pixel2 (:194-227; flags = SCSFM_C2P_OVERWRITE for padding_mode 'zeros',
  * z != NULL): cam [B,3,H,W], rot [B,3,3] or NULL, tr [B,3] or NULL -> grid [B,H,W,2] (store) and, optionally, the
  * clamped depth z [B,1,H,W] (store).  Backward: g_grid [B,H,W,2], g_z [B,1,H,W] or NULL -> g_cam [B,3,H,W] (store)
@@ -222,6 +249,11 @@ int scsfm_pixel2cam_fwd_f32(int B, int H, int W, const float* depth, const float
                             void* stream);
 int scsfm_pixel2cam_bwd_f32(int B, int H, int W, const float* intrinsics_inv, const float* g_cam, float* g_depth,
                             void* stream);
+/* dL/d intrinsics_inv [B,3,3] (store) of pixel2cam = sum over the pixels of g_cam (x) (u, v, 1) depth. */
+int scsfm_pixel2cam_bwd_intrinsics_f32(int B, int H, int W, const float* depth, const float* g_cam,
+                                       float* g_intrinsics_inv, void* stream);
+int scsfm_pixel2cam_bwd_intrinsics_f64(int B, int H, int W, const double* depth, const double* g_cam,
+                                       double* g_intrinsics_inv, void* stream);
 int scsfm_cam2pixel_fwd_f32(int B, int H, int W, const float* cam, const float* rot, const float* tr, unsigned flags,
                             float* grid, float* z, void* stream);
 int scsfm_cam2pixel_bwd_f32(int B, int H, int W, const float* cam, const float* rot, const float* tr, unsigned flags,
@@ -288,6 +320,12 @@ int scsfm_masked_mean_fwd_f64(int B, int C, int Cm, int HW, const double* diff, 
                               void* ws, double* out, void* stream);
 int scsfm_masked_mean_bwd_f64(int B, int C, int Cm, int HW, const double* mask, void* ws,
                               const double* g, double* g_diff, void* stream);
+/* ... and with respect to a floating-point mask [B,Cm,HW] (store; diff as in the forward, `ws` from it): the
+ * reference's autograd reaches the mask through both sums of mean_on_mask (loss_functions.py:123-129). */
+int scsfm_masked_mean_bwd_mask_f32(int B, int C, int Cm, int HW, const float* diff, void* ws, const float* g,
+                                   float* g_mask, void* stream);
+int scsfm_masked_mean_bwd_mask_f64(int B, int C, int Cm, int HW, const double* diff, void* ws, const double* g,
+                                   double* g_mask, void* stream);
 
 /* compute_smooth_loss (loss_functions.py:154-159): n frames per call.  depths / imgs / g_depths / edges
  * are HOST arrays of n DEVICE pointers; ws = n * scsfm_smooth_ws_bytes(B,H,W) bytes; out[n + 1] (device,
@@ -307,6 +345,15 @@ int scsfm_smooth_multi_fwd_f64(int n, const void* const* depths, const void* con
 int scsfm_smooth_multi_bwd_f64(int n, const void* const* depths, const void* const* imgs, int B, int H,
                                int W, void* ws, void* const* edges, const double* g_loss,
                                void* const* g_depths, int accumulate, void* stream);
+/* dL/d img of the same frames (the reference's autograd reaches the images through the edge weights
+ * exp(-mean_c |dI|), loss_functions.py:148-152; train.py never asks): g_imgs is a HOST array of n DEVICE pointers,
+ * each NULL (skip) or [B,3,H,W], stored -- or added to when `accumulate` is non-zero.  `ws` as left by the forward. */
+int scsfm_smooth_multi_bwd_images_f32(int n, const void* const* depths, const void* const* imgs, int B, int H,
+                                      int W, void* ws, const float* g_loss, void* const* g_imgs, int accumulate,
+                                      void* stream);
+int scsfm_smooth_multi_bwd_images_f64(int n, const void* const* depths, const void* const* imgs, int B, int H,
+                                      int W, void* ws, const double* g_loss, void* const* g_imgs, int accumulate,
+                                      void* stream);
 
 /* The weighted sum of a training step, loss = w_photo * photo + w_smooth * smooth + w_geom * geometry
  * (train.py:268), for callers that keep the three losses behind ONE autograd node:

@@ -140,6 +140,28 @@ __global__ __launch_bounds__(kThreads) void masked_mean_bwd_kernel(long n, int C
   }
 }
 
+// dL/d mask of mean_on_mask (the reference's autograd reaches a floating-point mask: out = sum(diff m) / sum(m) over
+// the EXPANDED mask, loss_functions.py:123-129): for an entry of the [B, Cm, HW] mask,
+//   g * sum over the channels it is expanded to of (diff / S - N / S^2),   N = sum(diff m), S = sum(m); 0 when gated off.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void masked_mean_bwd_mask_kernel(long nm, int C, int Cm, long HW,
+                                                                        const T* __restrict__ diff,
+                                                                        const double* __restrict__ ws,
+                                                                        const T* __restrict__ g, T* __restrict__ g_mask) {
+  const T inv = T(ws[2]), off = T(ws[0] * ws[2] * ws[2]), gg = g[0];
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < nm; i += (long)gridDim.x * kThreads) {
+    const long bc = i / HW, hw = i - bc * HW;
+    T v;
+    if (Cm == 1) {
+      v = T(0);
+      for (int c = 0; c < C; ++c) v += diff[(bc * C + c) * HW + hw] * inv - off;
+    } else {
+      v = diff[i] * inv - off;
+    }
+    g_mask[i] = inv != T(0) ? gg * v : T(0);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 template <typename T>
 static int ssim_fwd(int N, int H, int W, const T* x, const T* y, T* out, void* stream) {
@@ -179,6 +201,18 @@ static int masked_mean_bwd(int B, int C, int Cm, int HW, const T* mask, void* ws
   const int nb = (int)(n / (kThreads * 4) + 1 < 2048 ? n / (kThreads * 4) + 1 : 2048);
   hipLaunchKernelGGL((masked_mean_bwd_kernel<T>), dim3(nb), dim3(kThreads), 0, (hipStream_t)stream, n, C, Cm,
                      (long)HW, mask, (const double*)ws, g, g_diff);
+  return launch_status();
+}
+
+template <typename T>
+static int masked_mean_bwd_mask(int B, int C, int Cm, int HW, const T* diff, void* ws, const T* g, T* g_mask,
+                                void* stream) {
+  clear_status();
+  if (B <= 0 || C <= 0 || HW <= 0 || (Cm != 1 && Cm != C) || !diff || !ws || !g || !g_mask) return SCSFM_ERR_ARG;
+  const long nm = (long)B * Cm * HW;
+  const int nb = (int)(nm / (kThreads * 4) + 1 < 2048 ? nm / (kThreads * 4) + 1 : 2048);
+  hipLaunchKernelGGL((masked_mean_bwd_mask_kernel<T>), dim3(nb), dim3(kThreads), 0, (hipStream_t)stream, nm, C, Cm,
+                     (long)HW, diff, (const double*)ws, g, g_mask);
   return launch_status();
 }
 
@@ -234,6 +268,10 @@ size_t scsfm_masked_mean_ws_bytes(void) { return (4 + 2 * (size_t)scsfm::kMmBloc
   int scsfm_masked_mean_bwd_##SUF(int B, int C, int Cm, int HW, const T* mask, void* ws, const T* g, T* g_diff,       \
                                   void* stream) {                                                                     \
     return scsfm::masked_mean_bwd<T>(B, C, Cm, HW, mask, ws, g, g_diff, stream);                                      \
+  }                                                                                                                   \
+  int scsfm_masked_mean_bwd_mask_##SUF(int B, int C, int Cm, int HW, const T* diff, void* ws, const T* g, T* g_mask,  \
+                                       void* stream) {                                                                \
+    return scsfm::masked_mean_bwd_mask<T>(B, C, Cm, HW, diff, ws, g, g_mask, stream);                                 \
   }                                                                                                                   \
   int scsfm_step_total_##SUF(const T* photo_geom, const T* smooth, double w_photo, double w_smooth, double w_geom,    \
                              T* out, void* stream) {                                                                  \

@@ -130,16 +130,34 @@ __device__ __forceinline__ void pose_from_gP(const T* __restrict__ k, const T* _
   o[3] = ga[0]; o[4] = ga[1]; o[5] = ga[2];
 }
 
-// gP [B][12] accumulated with atomics (warp_bwd path); re-zeroed after use.
+// gP [B][12] accumulated with atomics (warp_bwd path: zeroed before the accumulation, left in the workspace for
+// scsfm_warp_bwd_inputs).
 template <typename T>
 __global__ void pose_bwd_kernel(int B, const T* __restrict__ pose, const T* __restrict__ K,
-                                double* __restrict__ gP, T* __restrict__ gpose, int quat) {
+                                const double* __restrict__ gP, T* __restrict__ gpose, int quat) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   double g[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) { g[i] = gP[12 * b + i]; gP[12 * b + i] = 0.0; }  // consumed: ready for the next backward
+  for (int i = 0; i < 12; ++i) g[i] = gP[12 * b + i];
   pose_from_gP(K + 9 * b, pose + 6 * b, g, gpose + 6 * b, quat != 0);
+}
+template <typename T> __device__ __forceinline__ void intrinsics_from_gP(const T* __restrict__ k, const T* __restrict__ p,
+                                                                         const double* g, bool quat, double* gK);
+// ... and dL/d intrinsics [B,3,3] (store) from the same sums.
+template <typename T>
+__global__ void intrinsics_bwd_kernel(int B, const T* __restrict__ pose, const T* __restrict__ K,
+                                      const double* __restrict__ gP, T* __restrict__ gK, int quat) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double g[12], o[9];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) g[i] = gP[12 * b + i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o[i] = 0.0;
+  intrinsics_from_gP(K + 9 * b, pose + 6 * b, g, quat != 0, o);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) gK[9 * b + i] = T(o[i]);
 }
 
 // One wave per batch element: ordered fp64 reduction of the per-block partials gPp[b][nblk][12]
@@ -147,15 +165,13 @@ __global__ void pose_bwd_kernel(int B, const T* __restrict__ pose, const T* __re
 // when both upstream coefficients are zero and then leaves the partials untouched).
 template <typename T> struct BatchConsts;
 template <typename T, typename A> __device__ __forceinline__ void pose_partials_to_A(const BatchConsts<T>& bc, A* acc);
+// The 12 sums of one (pair, batch element): ordered fp64 reduction of the per-block partials (one wave), times the
+// factor they still lack, converted from sums against the pixel-frame point to dL/dA (g[0..8]) | dL/dc (g[9..11]).
+// Valid in lane 0.
 template <typename T>
-__device__ __forceinline__ void pose_reduce_one(int b, int nblk, double scale, const T* __restrict__ pose,
-                                                const T* __restrict__ K, const BatchConsts<T>* __restrict__ consts,
-                                                const double* __restrict__ gPp,
-                                                const double* __restrict__ sums, const T* __restrict__ g_photo,
-                                                const T* __restrict__ g_geom, T* __restrict__ gpose) {
+__device__ __forceinline__ void pose_partials_sum(int b, int nblk, double scale, const BatchConsts<T>* __restrict__ consts,
+                                                  const double* __restrict__ gPp, bool live, double (&g)[12]) {
   const int lane = threadIdx.x & (kWave - 1);  // one wave per call (of a 64-thread or a larger workgroup)
-  const bool live = !(T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0));
-  double g[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) g[i] = 0.0;
   if (live) {
@@ -167,11 +183,61 @@ __device__ __forceinline__ void pose_reduce_one(int b, int nblk, double scale, c
 #pragma unroll
     for (int i = 0; i < 12; ++i) g[i] = wave_sum(g[i]) * scale;
   }
-  if (lane == 0) {
-    // the partials are sums against the pixel-frame point depth * (u, v, 1): dL/dA = G K^-T, once per image
-    pose_partials_to_A(consts[b], g);
-    pose_from_gP(K + 9 * b, pose + 6 * b, g, gpose + 6 * b);
+  // the partials are sums against the pixel-frame point depth * (u, v, 1): dL/dA = G K^-T, once per image
+  if (lane == 0) pose_partials_to_A(consts[b], g);
+}
+
+template <typename T>
+__device__ __forceinline__ void pose_reduce_one(int b, int nblk, double scale, const T* __restrict__ pose,
+                                                const T* __restrict__ K, const BatchConsts<T>* __restrict__ consts,
+                                                const double* __restrict__ gPp,
+                                                const double* __restrict__ sums, const T* __restrict__ g_photo,
+                                                const T* __restrict__ g_geom, T* __restrict__ gpose) {
+  const bool live = !(T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0));
+  double g[12];
+  pose_partials_sum(b, nblk, scale, consts, gPp, live, g);
+  if ((threadIdx.x & (kWave - 1)) == 0) pose_from_gP(K + 9 * b, pose + 6 * b, g, gpose + 6 * b);
+}
+
+// dL/d intrinsics of one batch element from dL/dA | dL/dc.  K enters the warp twice (inverse_warp.py:253-260): the
+// camera point is K^-1 (u, v, 1) depth and the projection is (A | c) = K [R | t], so with G = dL/dA, gc = dL/dc
+//   dL/dK = G R^T + gc t^T                       (A = K R, c = K t)
+//         - K^-T R^T K^T G                       (through torch.inverse: -K^-T (dL/dK^-1) K^-T with dL/dK^-1 = A^T P
+//                                                 and P = G K^T the sums against the pixel-frame point)
+// evaluated in fp64 and ADDED to gK[9] (row-major).  The reference's autograd produces exactly these nine numbers,
+// structural zeros of K included.
+template <typename T>
+__device__ __forceinline__ void intrinsics_from_gP(const T* __restrict__ k, const T* __restrict__ p, const double* g,
+                                                   bool quat, double* gK) {
+  double Kd[9], R[9], N[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Kd[i] = double(k[i]);
+  if (quat) quat_to_R(double(p[3]), double(p[4]), double(p[5]), R); else euler_to_R(double(p[3]), double(p[4]), double(p[5]), R);
+  {
+    const double a = Kd[0], bb = Kd[1], c = Kd[2], d = Kd[3], e = Kd[4], f = Kd[5], gg = Kd[6], h = Kd[7], i = Kd[8];
+    const double C00 = e * i - f * h, C01 = -(d * i - f * gg), C02 = d * h - e * gg;
+    const double inv = 1.0 / (a * C00 + bb * C01 + c * C02);
+    N[0] = C00 * inv; N[1] = -(bb * i - c * h) * inv; N[2] = (bb * f - c * e) * inv;
+    N[3] = C01 * inv; N[4] = (a * i - c * gg) * inv;  N[5] = -(a * f - c * d) * inv;
+    N[6] = C02 * inv; N[7] = -(a * h - bb * gg) * inv; N[8] = (a * e - bb * d) * inv;
   }
+  double X[9], Y[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) X[3 * a + b] = Kd[a] * g[b] + Kd[3 + a] * g[3 + b] + Kd[6 + a] * g[6 + b];  // K^T G
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) Y[3 * a + b] = R[a] * X[b] + R[3 + a] * X[3 + b] + R[6 + a] * X[6 + b];      // R^T (K^T G)
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const double through_inverse = N[a] * Y[b] + N[3 + a] * Y[3 + b] + N[6 + a] * Y[6 + b];              // K^-T (...)
+      const double left = g[3 * a] * R[3 * b] + g[3 * a + 1] * R[3 * b + 1] + g[3 * a + 2] * R[3 * b + 2];   // G R^T
+      gK[3 * a + b] += left + g[9 + a] * double(p[b]) - through_inverse;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -369,10 +369,20 @@ __global__ __launch_bounds__(March<T>::kWaves * kWave, sizeof(T) == 4 ? SCSFM_MA
 #endif
 
 // One tile of pass A (blk = logical tile of an nbx x nby x (pairs * B) tiling).
-template <typename T, bool kSsim, bool kScaled>
+// kImages (scsfm_pairs_bwd_inputs): the same pass produces the gradients of the two IMAGES instead of the planes for
+// pass B -- dL/d(warped colour) is splatted over the reference image's taps (grid_sampler_2d_backward on its input,
+// inverse_warp.py:262), and dL/d(target colour) -- the x side of the SSIM term, whose E[x^2] and E[xy] maps are those of
+// the y side, and the L1 term with the opposite sign -- is added to the target image's gradient.  Atomic adds: an image
+// is the target of one pair-direction and the reference of another.
+template <typename T>
+struct ImageGrads {
+  T* tgt[kMaxPairs];
+  T* ref[kMaxPairs];
+};
+template <typename T, bool kSsim, bool kScaled, bool kImages = false>
 __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, const PairBatch<T>& pb, int B, int H,
                                            int W, unsigned flags, const T* __restrict__ g_photo,
-                                           const T* __restrict__ g_geom) {
+                                           const T* __restrict__ g_geom, const ImageGrads<T>* ig = nullptr) {
   const int pair = blk.z / B, b = blk.z - pair * B;
   const PairArgs<T>& pa = pb.p[pair];
   const T* __restrict__ tgt_img = pa.tgt_img;
@@ -383,13 +393,18 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
   typedef typename Vec2<T>::type V2;
   constexpr int TH = Tile<T>::kH, STRIP = TH / (kThreads / kWave);
   __shared__ V2 sXY[kSsim ? 3 : 1][kSsim ? TH + 2 : 1][kSsim ? kHaloW : 1];
-  __shared__ T sG[kSsim ? 3 : 1][kSsim ? TH : 1][kSsim ? kTileW : 1];  // 1/9 (g_mu_y, g_E[y^2], g_E[xy]), one colour
+  constexpr int NMAP = kImages ? 4 : 3;
+  __shared__ T sG[kSsim ? NMAP : 1][kSsim ? TH : 1][kSsim ? kTileW : 1];  // 1/9 (g_mu_y, g_E[y^2], g_E[xy] [, g_mu_x]), one colour
 
   // upstream gradient x d(masked mean)/d(sum): zero when the 10000-pixel gate was closed
   const T a = T(sums[5]) * g_photo[0];
   const T bg = T(sums[6]) * g_geom[0];
   if (a == T(0) && bg == T(0)) return;        // workgroup-uniform: pass B skips as well
-  if (spec_valid(sums, g_photo, g_geom)) return;  // the forward already left the planes in gbuf
+  if (!kImages && spec_valid(sums, g_photo, g_geom)) return;  // the forward already left the planes in gbuf
+  T* __restrict__ gi_tgt = kImages ? ig->tgt[pair] : nullptr;
+  T* __restrict__ gi_ref = kImages ? ig->ref[pair] : nullptr;
+  if (kImages && !gi_tgt && !gi_ref) return;
+  Sample<T> ss[kImages ? STRIP : 1];
 
   const int col = threadIdx.x & (kWave - 1), strip = threadIdx.x / kWave;
   // the 64 x TH compute domain starts one pixel before the 62 x (TH-2) block of outputs
@@ -432,6 +447,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
     const int v = reflect_index(py, H);
     V2 xy[3];
     const Sample<T> s = warp_colours(bc, u, v, in_d[k], in_t[k], H, W, flags, ref_img, xy);
+    if constexpr (kImages) ss[k] = s;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       if constexpr (kSsim) sXY[c][ly + 1][col + 1] = xy[c]; else cen[k][c] = xy[c];
@@ -455,7 +471,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
   // ---- phases 2/3, one colour channel at a time ------------------------------------------------
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    T gI[STRIP];
+    T gI[STRIP], gIt[kImages ? STRIP : 1];
     if constexpr (kSsim) {
       // phase 2: forward statistics at every owned pixel q; publish 1/9 (g_mu_y, g_E[y^2], g_E[xy])(q)
       WinSums<T> ws[STRIP];
@@ -471,11 +487,12 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
         ssim_grad_y(st, gS, g1, g2, g3);
         const int ly = strip * STRIP + k;
         sG[0][ly][col] = g1; sG[1][ly][col] = g2; sG[2][ly][col] = g3;
+        if constexpr (kImages) { T g1x; ssim_grad_x(st, gS, g1x); sG[NMAP - 1][ly][col] = g1x; }
       }
       __syncthreads();
       // phase 3: transpose of (reflect-pad + 3x3 box) as a separable 3x3 gather
-      T gt[STRIP][3];
-      strip_box_transpose<T, STRIP, TH, 3>(sG, strip * STRIP, col, px, py0, H, W, gt);
+      T gt[STRIP][NMAP];
+      strip_box_transpose<T, STRIP, TH, NMAP>(sG, strip * STRIP, col, px, py0, H, W, gt);
 #pragma unroll
       for (int k = 0; k < STRIP; ++k) {
         const T x = centre[k][0], y = centre[k][1], d = x - y;
@@ -483,6 +500,7 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
         // d clamp(|d|, 0, 1) / d Iw: the clamp passes gradient on [0, 1] inclusive, abs uses sgn
         const T l1g = (t_abs(d) <= T(1)) ? -t_sgn(d) : T(0);
         gI[k] = gt[k][0] + T(2) * y * gt[k][1] + x * gt[k][2] + coef[k] * T(0.15) * l1g;
+        if constexpr (kImages) gIt[k] = gt[k][NMAP - 1] + T(2) * x * gt[k][1] + y * gt[k][2] - coef[k] * T(0.15) * l1g;
       }
       if (c < 2) __syncthreads();  // sG is rewritten by the next colour
     } else {
@@ -491,16 +509,25 @@ __device__ __forceinline__ void photo_tile(const BlockId blk, int nbx, int nby, 
         const T d = cen[k][c][0] - cen[k][c][1];
         bsum[k] += clamp01(t_abs(d));
         gI[k] = coef[k] * ((t_abs(d) <= T(1)) ? -t_sgn(d) : T(0));
+        if constexpr (kImages) gIt[k] = -gI[k];
       }
     }
 #pragma unroll
     for (int k = 0; k < STRIP; ++k) {
       const int ly = strip * STRIP + k, py = py0 + k;
       // note: m(p) = 0 still receives SSIM gradient through its neighbours' windows
-      if (in_x && ly >= 1 && ly <= TH - 2 && py < H)
-        st_at(gbuf + (kPlaneGI + c) * gplane, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gI[k]);
+      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) {
+        if constexpr (kImages) {
+          const size_t cplane = ((size_t)b * 3 + c) * plane;
+          if (gi_tgt) atomicAdd(gi_tgt + cplane + unsigned(py) * unsigned(W) + unsigned(px), gIt[k]);
+          if (gi_ref) scatter_taps(gi_ref + cplane, ss[k], gI[k]);
+        } else {
+          st_at(gbuf + (kPlaneGI + c) * gplane, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gI[k]);
+        }
+      }
     }
   }
+  if constexpr (kImages) return;
   // dL/d diff_depth: directly (geometry loss) and through the weight mask (no detach, loss_functions.py:111-113);
   // handed to pass B.  This tile's part of the pair's scatter plane is cleared on the way (pass B only runs when
   // this pass did)
@@ -533,6 +560,14 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 3 : 1) void pair_bwd_pho
     photo_tile<T, kSsim, kScaled>(blk, nbx, nby, pb, B, H, W, flags, g_photo, g_geom);
     __syncthreads();  // the tile's LDS is reused
   }
+}
+
+// The image gradients of up to kMaxPairs pair-directions (scsfm_pairs_bwd_inputs): one tile per workgroup.
+template <typename T, bool kSsim, bool kScaled>
+__global__ __launch_bounds__(kThreads) void pair_bwd_images_kernel(PairBatch<T> pb, ImageGrads<T> ig, int B, int H, int W,
+                                                                   unsigned flags, const T* __restrict__ g_photo,
+                                                                   const T* __restrict__ g_geom) {
+  photo_tile<T, kSsim, kScaled, true>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, pb, B, H, W, flags, g_photo, g_geom, &ig);
 }
 
 // ==========================================================================================
@@ -677,6 +712,32 @@ __global__ void pairs_pose_reduce_kernel(PairBatch<T> pb, int B, int nblk_geom, 
   pose_reduce_one(b, spec ? int(pa.sums[11]) : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K, pa.consts,
                   pa.gPp, pa.sums, g_photo, g_geom, pa.g_pose);
   if (b == 0 && threadIdx.x == 0) retire_speculation(pa.sums, g_photo, g_geom);
+}
+
+// dL/d intrinsics [B,3,3] of up to kMaxPairs pair-directions: one wave per batch element re-reduces every pair's pose
+// partials (still in the workspaces after scsfm_pairs_bwd, in the state pairs_pose_reduce_kernel found them) and adds
+// up the pairs' contributions in pair order (fp64).
+template <typename T>
+__global__ void pairs_intrinsics_kernel(PairBatch<T> pb, int npairs, int B, int nblk_geom, const T* __restrict__ K,
+                                        const T* __restrict__ g_photo, const T* __restrict__ g_geom, T* __restrict__ gK,
+                                        int accumulate) {
+  const int b = blockIdx.x;
+  double tot[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) tot[i] = 0.0;
+  for (int p = 0; p < npairs; ++p) {
+    const PairArgs<T>& pa = pb.p[p];
+    const bool spec = spec_valid(pa.sums, g_photo, g_geom);
+    const bool live = !(T(pa.sums[5]) * g_photo[0] == T(0) && T(pa.sums[6]) * g_geom[0] == T(0));
+    double g[12];
+    pose_partials_sum(b, spec ? int(pa.sums[11]) : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.consts, pa.gPp,
+                      live, g);
+    if (threadIdx.x == 0) intrinsics_from_gP(K + 9 * b, pa.pose + 6 * b, g, false, tot);
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gK[9 * b + i] = accumulate ? gK[9 * b + i] + T(tot[i]) : T(tot[i]);
+  }
 }
 
 // dst[d] (+)= sum_k scale_k * src_k: the dense planes of the pairs whose target depth map dst is and the scatter
@@ -1104,6 +1165,49 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
   return launch_status();
 }
 
+// Gradients of the DATA inputs of the pair losses (images, intrinsics): the reference's autograd reaches them
+// (inverse_warp.py:253-262, loss_functions.py:99-108) although train.py never asks.  After pairs_bwd, same arguments.
+template <typename T>
+static int pairs_bwd_inputs(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,
+                            const T* g_photo, const T* g_geom, T* g_K, void* stream_) {
+  clear_status();
+  if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !K || !g_photo || !g_geom) return SCSFM_ERR_ARG;
+  for (int i = 0; i < n; ++i)
+    if (!desc_inputs_ok(d[i], H, W)) return SCSFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  for (int i0 = 0; i0 < n; i0 += kMaxPairs) {
+    const int m = n - i0 < kMaxPairs ? n - i0 : kMaxPairs;
+    PairBatch<T> pb;
+    ImageGrads<T> ig;
+    bool full_res = true, any_img = false;
+    for (int i = 0; i < kMaxPairs; ++i) { ig.tgt[i] = nullptr; ig.ref[i] = nullptr; }
+    for (int i = 0; i < m; ++i) {
+      pb.p[i] = make_pair_args<T>(d[i0 + i], B, H, W, nullptr, i0 + i);
+      full_res = full_res && d[i0 + i].depth_shift == 0;
+      ig.tgt[i] = (T*)d[i0 + i].g_tgt_img; ig.ref[i] = (T*)d[i0 + i].g_ref_img;
+      any_img = any_img || ig.tgt[i] || ig.ref[i];
+    }
+    if (any_img) {
+      const dim3 grid(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), m * B);
+#define SCSFM_LAUNCH_IMAGES(SSIM, SCALED)                                                                             \
+  hipLaunchKernelGGL((pair_bwd_images_kernel<T, SSIM, SCALED>), grid, dim3(kThreads), 0, stream, pb, ig, B, H, W, flags, \
+                     g_photo, g_geom)
+      if (flags & SCSFM_WITH_SSIM) {
+        if (full_res) SCSFM_LAUNCH_IMAGES(true, false); else SCSFM_LAUNCH_IMAGES(true, true);
+      } else {
+        if (full_res) SCSFM_LAUNCH_IMAGES(false, false); else SCSFM_LAUNCH_IMAGES(false, true);
+      }
+#undef SCSFM_LAUNCH_IMAGES
+    }
+    if (g_K) {
+      const int nbx = ceil_div(W, kWave), nby = ceil_div(H, kGeomRows * (kThreads / kWave));
+      hipLaunchKernelGGL((pairs_intrinsics_kernel<T>), dim3(B), dim3(kWave), 0, stream, pb, m, B, nbx * nby, K, g_photo,
+                         g_geom, g_K, i0 > 0 ? 1 : 0);
+    }
+  }
+  return launch_status();
+}
+
 template <typename T>
 static int pair_refinalize(int B, int H, int W, void* ws, T* out, void* stream) {
   clear_status();
@@ -1123,6 +1227,7 @@ static scsfm_pair_desc one_desc(const T* tgt_img, const T* ref_img, const T* tgt
   d.total = nullptr;
   d.hint = nullptr;
   d.depth_shift = 0;
+  d.g_tgt_img = nullptr; d.g_ref_img = nullptr;
   return d;
 }
 
@@ -1184,6 +1289,10 @@ size_t scsfm_pair_ws_bytes(int B, int H, int W) {
   int scsfm_pairs_bwd_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,          \
                             void* scratch, const T* g_photo, const T* g_geom, void* stream) {                         \
     return scsfm::pairs_bwd<T>(n, d, B, H, W, K, flags, scratch, g_photo, g_geom, false, stream);                     \
+  }                                                                                                                   \
+  int scsfm_pairs_bwd_inputs_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,   \
+                                   const T* g_photo, const T* g_geom, T* g_intrinsics, void* stream) {                \
+    return scsfm::pairs_bwd_inputs<T>(n, d, B, H, W, K, flags, g_photo, g_geom, g_intrinsics, stream);                \
   }                                                                                                                   \
   int scsfm_pair_fwd_##SUF(int B, int H, int W, const T* tgt_img, const T* ref_img, const T* tgt_depth,               \
                            const T* ref_depth, const T* pose, const T* K, unsigned flags, void* ws, T* out,           \

@@ -250,6 +250,42 @@ __global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(SmoothBatch<T> sb,
   }
 }
 
+// dL/d img of get_smooth_loss (the reference's autograd reaches the image through the edge weights; train.py never
+// asks): with t(p, q) = |D(p) - D(q)| exp(-mean_c |I_c(p) - I_c(q)|) / (den_b cnt) for the edge (p, q),
+//   dL/dI_c(p) = g * sum over the (up to four) edges of p of  -+ t / 3 * sgn(I_c(first) - I_c(second))
+// (- for the edge's first pixel, + for its second; abs has the sub-gradient 0 at 0).  One thread per pixel, plain
+// loads, stores (or accumulates): not a hot path.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void smooth_bwd_images_kernel(SmoothBatch<T> sb, int B, int H, int W,
+                                                                     const T* __restrict__ g_loss, int accumulate) {
+  const int frame = blockIdx.z / B, b = blockIdx.z - frame * B;
+  const SmoothFrame<T>& fr = sb.f[frame];
+  if (!fr.g_depth) return;  // (g_depth carries this frame's IMAGE gradient buffer in this launch; workgroup-uniform)
+  const int x = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const int y = blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave;
+  if (x >= W || y >= H) return;
+  const unsigned plane = unsigned(H) * unsigned(W);
+  const T* __restrict__ depth = fr.depth + (size_t)b * plane;
+  const T* __restrict__ img = fr.img + (size_t)b * 3 * plane;
+  T* __restrict__ g_img = fr.g_depth + (size_t)b * 3 * plane;
+  const T third = T(1.0 / 3.0);
+  const T sx = g_loss[0] * T(1.0 / (fr.per_img[2 * b] * (double)B * H * (W - 1))) * third;
+  const T sy = g_loss[0] * T(1.0 / (fr.per_img[2 * b] * (double)B * (H - 1) * W)) * third;
+  const unsigned p = unsigned(y) * unsigned(W) + unsigned(x);
+  const Px<T> cur = load_px(depth, img, plane, p);
+  T acc[3] = {T(0), T(0), T(0)};
+  auto edge = [&](const Px<T>& first, const Px<T>& second, T scale, T side) {  // side: -1 = cur is `first`, +1 = `second`
+    const T t = t_abs(first.d - second.d) * edge_weight(first, second) * scale * side;
+    acc[0] += t * t_sgn(first.c0 - second.c0); acc[1] += t * t_sgn(first.c1 - second.c1); acc[2] += t * t_sgn(first.c2 - second.c2);
+  };
+  if (x + 1 < W) edge(cur, load_px(depth, img, plane, p + 1), sx, T(-1));
+  if (x > 0) edge(load_px(depth, img, plane, p - 1), cur, sx, T(1));
+  if (y + 1 < H) edge(cur, load_px(depth, img, plane, p + unsigned(W)), sy, T(-1));
+  if (y > 0) edge(load_px(depth, img, plane, p - unsigned(W)), cur, sy, T(1));
+#pragma unroll
+  for (int c = 0; c < 3; ++c) g_img[c * plane + p] = accumulate ? g_img[c * plane + p] + acc[c] : acc[c];
+}
+
 template <typename T>
 static SmoothFrame<T> make_frame(int B, int H, int W, const void* depth, const void* img, void* ws, T* out, void* g_depth,
                                  void* edge) {
@@ -313,6 +349,28 @@ static int smooth_multi_bwd(int n, const void* const* depths, const void* const*
   return launch_status();
 }
 
+template <typename T>
+static int smooth_multi_bwd_images(int n, const void* const* depths, const void* const* imgs, int B, int H, int W, void* ws,
+                                   const T* g_loss, void* const* g_imgs, bool accumulate, void* stream_) {
+  clear_status();
+  if (n < 0 || B <= 0 || H < 2 || W < 2 || (n > 0 && (!depths || !imgs || !ws || !g_loss || !g_imgs))) return SCSFM_ERR_ARG;
+  for (int i = 0; i < n; ++i)
+    if (!depths[i] || !imgs[i]) return SCSFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const SmoothWs l = smooth_ws_layout(B, H, W);
+  for (int i0 = 0; i0 < n; i0 += kMaxFrames) {
+    const int m = n - i0 < kMaxFrames ? n - i0 : kMaxFrames;
+    SmoothBatch<T> sb;
+    for (int i = 0; i < m; ++i)
+      sb.f[i] = make_frame<T>(B, H, W, depths[i0 + i], imgs[i0 + i], (char*)ws + (size_t)(i0 + i) * l.total, nullptr,
+                              g_imgs[i0 + i], nullptr);
+    sb.counter = nullptr; sb.total = nullptr; sb.first = 0;
+    hipLaunchKernelGGL((smooth_bwd_images_kernel<T>), dim3(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), m * B),
+                       dim3(kThreads), 0, stream, sb, B, H, W, g_loss, accumulate ? 1 : 0);
+  }
+  return launch_status();
+}
+
 }  // namespace scsfm
 
 extern "C" {
@@ -332,6 +390,11 @@ size_t scsfm_smooth_ws_bytes(int B, int H, int W) {
                                    int accumulate, void* stream) {                                                   \
     return scsfm::smooth_multi_bwd<T>(n, depths, imgs, B, H, W, ws, edges, g_loss, g_depths, accumulate != 0,        \
                                       stream);                                                                       \
+  }                                                                                                                  \
+  int scsfm_smooth_multi_bwd_images_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H,   \
+                                          int W, void* ws, const T* g_loss, void* const* g_imgs, int accumulate,     \
+                                          void* stream) {                                                            \
+    return scsfm::smooth_multi_bwd_images<T>(n, depths, imgs, B, H, W, ws, g_loss, g_imgs, accumulate != 0, stream);  \
   }                                                                                                                  \
   int scsfm_smooth_fwd_##SUF(int B, int H, int W, const T* depth, const T* img, void* ws, T* out, void* stream) {    \
     const void* d = depth; const void* im = img;                                                                     \

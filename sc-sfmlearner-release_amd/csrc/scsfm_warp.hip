@@ -75,6 +75,23 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(
   }
 }
 
+// dL/d(sampled image) of inverse_warp2 / inverse_warp: the bilinear splat of dL/d(projected image)
+// (grid_sampler_2d_backward on its input; inverse_warp.py:262).  Accumulates with atomics.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void warp_bwd_image_kernel(int H, int W, unsigned flags, const T* __restrict__ depth,
+                                                                  const BatchConsts<T>* __restrict__ consts,
+                                                                  const T* __restrict__ g_img, T* __restrict__ g_src) {
+  const int b = blockIdx.z;
+  const int u = blockIdx.x * kWave + (threadIdx.x & (kWave - 1));
+  const int v = blockIdx.y * (kThreads / kWave) + threadIdx.x / kWave;
+  if (u >= W || v >= H) return;
+  const BatchConsts<T> bc = consts[b];
+  const long plane = (long)H * W, p = (long)v * W + u;
+  const Sample<T> s = project_pixel(bc, u, v, depth[b * plane + p], H, W, flags);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) scatter_taps(g_src + (b * 3 + c) * plane, s, g_img[(b * 3 + c) * plane + p]);
+}
+
 // pose_vec2mat forward / backward, one thread per batch element.
 template <typename T>
 __global__ void pose_mat_fwd_kernel(int B, int mode, const T* __restrict__ vec, T* __restrict__ mat) {
@@ -152,6 +169,29 @@ static int warp_bwd(int B, int H, int W, const T* img, const T* depth, const T* 
   return launch_status();
 }
 
+// The gradients of the warp's DATA inputs (the reference's autograd reaches them; train.py never asks): after
+// warp_bwd on the same workspace.
+template <typename T>
+static int warp_bwd_inputs(int B, int H, int W, const T* depth, const T* pose, const T* K, unsigned flags, void* ws,
+                           const T* g_img, T* g_src, T* g_K, void* stream_) {
+  clear_status();
+  if (B <= 0 || H < 2 || W < 2 || !pose || !K || !ws || (g_src && (!g_img || !depth))) return SCSFM_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  auto* consts = reinterpret_cast<BatchConsts<T>*>(ws);
+  const int quat = (flags & SCSFM_ROT_QUAT_FLAG) ? 1 : 0;
+  if (g_src) {
+    hipLaunchKernelGGL((prep_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, consts, quat);
+    dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
+    hipLaunchKernelGGL((warp_bwd_image_kernel<T>), grid, dim3(kThreads), 0, stream, H, W, flags, depth,
+                       (const BatchConsts<T>*)consts, g_img, g_src);
+  }
+  if (g_K) {
+    const double* gP = reinterpret_cast<const double*>(reinterpret_cast<const char*>(ws) + warp_ws_gP_offset(B));
+    hipLaunchKernelGGL((intrinsics_bwd_kernel<T>), dim3(ceil_div(B, 64)), dim3(64), 0, stream, B, pose, K, gP, g_K, quat);
+  }
+  return launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------------
 // pixel2cam (inverse_warp.py:29-44): cam[b, :, v, u] = K^-1_b (u, v, 1) * depth[b, v, u]
 // ------------------------------------------------------------------------------------------------------
@@ -183,6 +223,34 @@ __global__ __launch_bounds__(kThreads) void pixel2cam_bwd_kernel(int H, int W, c
 #pragma unroll
   for (int i = 0; i < 3; ++i) g += (k[3 * i] * uf + k[3 * i + 1] * vf + k[3 * i + 2]) * g_cam[(b * 3 + i) * plane + p];
   g_depth[b * plane + p] = g;
+}
+
+// dL/d intrinsics_inv [B,3,3] (store) = sum_p dL/d cam(p) (x) (u, v, 1) depth(p): one workgroup per batch element, fp64 sums.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pixel2cam_bwd_intrinsics_kernel(int H, int W, const T* __restrict__ depth,
+                                                                            const T* __restrict__ g_cam,
+                                                                            T* __restrict__ g_Kinv) {
+  __shared__ double red[9 * (kThreads / kWave)];
+  const int b = blockIdx.x;
+  const long plane = (long)H * W;
+  double acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) acc[i] = 0.0;
+  for (long p = threadIdx.x; p < plane; p += kThreads) {
+    const int v = int(p / W), u = int(p - (long)v * W);
+    const double d = double(depth[b * plane + p]);
+    const double q[3] = {double(u) * d, double(v) * d, d};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double g = double(g_cam[(b * 3 + i) * plane + p]);
+      acc[3 * i] += g * q[0]; acc[3 * i + 1] += g * q[1]; acc[3 * i + 2] += g * q[2];
+    }
+  }
+  block_sum<9>(acc, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g_Kinv[9 * b + i] = T(acc[i]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -292,6 +360,14 @@ static int pixel2cam_bwd(int B, int H, int W, const T* Kinv, const T* g_cam, T* 
   return launch_status();
 }
 template <typename T>
+static int pixel2cam_bwd_intrinsics(int B, int H, int W, const T* depth, const T* g_cam, T* g_Kinv, void* stream) {
+  clear_status();
+  if (B <= 0 || H < 1 || W < 1 || !depth || !g_cam || !g_Kinv) return SCSFM_ERR_ARG;
+  hipLaunchKernelGGL((pixel2cam_bwd_intrinsics_kernel<T>), dim3(B), dim3(kThreads), 0, (hipStream_t)stream, H, W, depth, g_cam,
+                     g_Kinv);
+  return launch_status();
+}
+template <typename T>
 static int cam2pixel_fwd(int B, int H, int W, const T* cam, const T* rot, const T* tr, unsigned flags, T* grid_out, T* z_out,
                          void* stream) {
   clear_status();
@@ -336,7 +412,7 @@ static int pose_bwd(int B, const T* vec, int mode, const T* g_mat, T* g_vec, voi
 
 extern "C" {
 
-int scsfm_abi_version(void) { return 6; }
+int scsfm_abi_version(void) { return 7; }
 
 #ifndef SCSFM_SOURCE_ID
 #define SCSFM_SOURCE_ID "unknown"
@@ -368,11 +444,20 @@ size_t scsfm_warp_ws_bytes(int B) {
     return scsfm::warp_bwd<T>(B, H, W, img, depth, ref_depth, pose, K, flags, ws, g_img, g_pd, g_cd, g_depth,         \
                               g_ref_depth, g_pose, stream);                                                           \
   }                                                                                                                   \
+  int scsfm_warp_bwd_inputs_##SUF(int B, int H, int W, const T* depth, const T* pose, const T* K, unsigned flags,     \
+                                  void* ws, const T* g_projected_img, T* g_img, T* g_intrinsics, void* stream) {      \
+    return scsfm::warp_bwd_inputs<T>(B, H, W, depth, pose, K, flags, ws, g_projected_img, g_img, g_intrinsics,        \
+                                     stream);                                                                         \
+  }                                                                                                                   \
   int scsfm_pixel2cam_fwd_##SUF(int B, int H, int W, const T* depth, const T* Kinv, T* cam, void* stream) {           \
     return scsfm::pixel2cam_fwd<T>(B, H, W, depth, Kinv, cam, stream);                                               \
   }                                                                                                                   \
   int scsfm_pixel2cam_bwd_##SUF(int B, int H, int W, const T* Kinv, const T* g_cam, T* g_depth, void* stream) {       \
     return scsfm::pixel2cam_bwd<T>(B, H, W, Kinv, g_cam, g_depth, stream);                                           \
+  }                                                                                                                   \
+  int scsfm_pixel2cam_bwd_intrinsics_##SUF(int B, int H, int W, const T* depth, const T* g_cam, T* g_intrinsics_inv,  \
+                                           void* stream) {                                                            \
+    return scsfm::pixel2cam_bwd_intrinsics<T>(B, H, W, depth, g_cam, g_intrinsics_inv, stream);                       \
   }                                                                                                                   \
   int scsfm_cam2pixel_fwd_##SUF(int B, int H, int W, const T* cam, const T* rot, const T* tr, unsigned flags,         \
                                 T* grid, T* z, void* stream) {                                                        \

@@ -84,7 +84,7 @@ def warp_fwd(lib, img, depth, ref_depth, pose, K, flags):
     return o_img, o_valid, o_pd, o_cd
 
 
-def warp_bwd(lib, img, depth, ref_depth, pose, K, flags, g_img, g_pd, g_cd):
+def warp_bwd(lib, img, depth, ref_depth, pose, K, flags, g_img, g_pd, g_cd, need_img=False, need_K=False):
     _chk(img, depth, ref_depth, pose, K, g_img, g_pd, g_cd)
     B, _, H, W = img.shape
     ws = _ws(lib, "scsfm_warp_ws_bytes", img, B)
@@ -93,7 +93,15 @@ def warp_bwd(lib, img, depth, ref_depth, pose, K, flags, g_img, g_pd, g_cd):
     g_pose = torch.empty_like(pose)
     lib.call(f"scsfm_warp_bwd_{_suffix(img)}", B, H, W, _p(img), _p(depth), _p(ref_depth), _p(pose), _p(K), flags,
              _p(ws), _p(g_img), _p(g_pd), _p(g_cd), _p(g_depth), _p(g_ref), _p(g_pose), _stream(img))
-    return g_depth, g_ref, g_pose
+    if not (need_img or need_K):
+        return g_depth, g_ref, g_pose
+    # the gradients of the data inputs (the reference's autograd reaches them): the bilinear splat of g_img into the
+    # sampled image, dL/d intrinsics from the sums the backward left in ws
+    g_src = torch.zeros_like(img) if (need_img and g_img is not None) else None
+    g_K = torch.empty_like(K) if need_K else None
+    lib.call(f"scsfm_warp_bwd_inputs_{_suffix(img)}", B, H, W, _p(depth), _p(pose), _p(K), flags, _p(ws), _p(g_img),
+             _p(g_src), _p(g_K), _stream(img))
+    return g_depth, g_ref, g_pose, g_src, g_K
 
 
 # -- pixel2cam / cam2pixel / cam2pixel2 ----------------------------------------------------------
@@ -183,6 +191,15 @@ def pair_refinalize(lib, shape, ws, out):
     lib.call(f"scsfm_pair_refinalize_{_suffix(out)}", B, H, W, _p(ws), _p(out), _stream(out))
 
 
+def pixel2cam_bwd_intrinsics(lib, depth, g_cam):
+    """dL/d intrinsics_inv [B,3,3] of pixel2cam."""
+    _chk(depth, g_cam)
+    B, _, H, W = g_cam.shape
+    g_kinv = torch.empty((B, 3, 3), dtype=g_cam.dtype, device=g_cam.device)
+    lib.call(f"scsfm_pixel2cam_bwd_intrinsics_{_suffix(g_cam)}", B, H, W, _p(depth), _p(g_cam), _p(g_kinv), _stream(g_cam))
+    return g_kinv
+
+
 def pair_bwd_scratch(lib, like, B, H, W):
     """Device scratch of one pair backward (dL/d warped colours + dL/d diff_depth between its two
     kernels); contents are irrelevant between calls, so consecutive calls on a stream may share it."""
@@ -190,7 +207,7 @@ def pair_bwd_scratch(lib, like, B, H, W):
 
 
 def pair_bwd(lib, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, ws, g_photo, g_geom,
-             g_tgt_depth=None, g_ref_depth=None, scratch=None):
+             g_tgt_depth=None, g_ref_depth=None, scratch=None, need_tgt_img=False, need_ref_img=False, need_K=False):
     """Accumulates into g_tgt_depth / g_ref_depth (allocated zeroed when None); returns them and
     g_pose [B,6]."""
     _chk(tgt_img, ref_img, tgt_depth, ref_depth, pose, K, g_photo, g_geom, g_tgt_depth, g_ref_depth)
@@ -205,7 +222,19 @@ def pair_bwd(lib, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, flags, ws, g_
     lib.call(f"scsfm_pair_bwd_{_suffix(tgt_img)}", B, H, W, _p(tgt_img), _p(ref_img), _p(tgt_depth), _p(ref_depth),
              _p(pose), _p(K), flags, _p(ws), _p(scratch), _p(g_photo), _p(g_geom), _p(g_tgt_depth), _p(g_ref_depth),
              _p(g_pose), _stream(tgt_img))
-    return g_tgt_depth, g_ref_depth, g_pose
+    if not (need_tgt_img or need_ref_img or need_K):
+        return g_tgt_depth, g_ref_depth, g_pose
+    d = (PairDesc * 1)()
+    d[0].tgt_img, d[0].ref_img, d[0].tgt_depth, d[0].ref_depth, d[0].pose = tgt_img.data_ptr(), ref_img.data_ptr(), \
+        tgt_depth.data_ptr(), ref_depth.data_ptr(), pose.data_ptr()
+    d[0].ws = ws.data_ptr()
+    g_ti = torch.zeros_like(tgt_img) if need_tgt_img else None
+    g_ri = torch.zeros_like(ref_img) if need_ref_img else None
+    g_K = torch.empty_like(K) if need_K else None
+    d[0].g_tgt_img, d[0].g_ref_img = _p(g_ti) or None, _p(g_ri) or None
+    lib.call(f"scsfm_pairs_bwd_inputs_{_suffix(tgt_img)}", 1, _ct.addressof(d), B, H, W, _p(K), flags, _p(g_photo),
+             _p(g_geom), _p(g_K), _stream(tgt_img))
+    return g_tgt_depth, g_ref_depth, g_pose, g_ti, g_ri, g_K
 
 
 # -- get_smooth_loss ---------------------------------------------------------------------------
@@ -272,6 +301,17 @@ def masked_mean_bwd(lib, diff_shape, mask, ws, g):
     return g_diff
 
 
+def masked_mean_bwd_mask(lib, diff, mask_shape, ws, g):
+    """dL/d mask (a floating-point mask is differentiable in the reference)."""
+    _chk(diff, g)
+    B, C = diff.shape[0], diff.shape[1]
+    HW = diff[0, 0].numel()
+    g_mask = torch.empty(mask_shape, dtype=diff.dtype, device=diff.device)
+    lib.call(f"scsfm_masked_mean_bwd_mask_{_suffix(diff)}", B, C, mask_shape[1], HW, _p(diff), _p(ws), _p(g), _p(g_mask),
+             _stream(diff))
+    return g_mask
+
+
 # -- compute_photo_and_geometry_loss: refs x scales x both directions ----------------------------
 import ctypes as _ct
 import functools as _ft
@@ -281,7 +321,7 @@ class PairDesc(_ct.Structure):
     """scsfm_pair_desc of include/scsfm_hip.h."""
     _fields_ = [(n, _ct.c_void_p) for n in ("tgt_img", "ref_img", "tgt_depth", "ref_depth", "pose", "ws", "out",
                                             "g_tgt_depth", "g_ref_depth", "g_pose", "gbuf", "total", "hint")] + \
-               [("depth_shift", _ct.c_int)]
+               [("depth_shift", _ct.c_int), ("g_tgt_img", _ct.c_void_p), ("g_ref_img", _ct.c_void_p)]
 
 
 def depth_shift(shape, B, H, W):
@@ -395,11 +435,13 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
 
 
 def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws, g_photo,
-                       g_geom, hint_dev=None):
+                       g_geom, hint_dev=None, need_imgs=None, need_K=False):
     """Gradients of photo_geometry_fwd's two sums: (g_tgt_depths[s], g_ref_depths[i][s], g_poses[i],
     g_poses_inv[i]).  Each depth map's gradient buffer receives the sum over every pair-direction that
     touches it (dense as target, scattered as reference) from the library's combining kernel, which
-    stores (no zero-fill); one call into the library, one shared scratch buffer."""
+    stores (no zero-fill); one call into the library, one shared scratch buffer.
+    ``need_imgs`` (one bool per image: target, then the references) / ``need_K``: also the gradients of the data inputs
+    -> two more results, ([g_tgt_img, g_ref_imgs...] with None where not wanted, g_K)."""
     B, _, H, W = tgt_img.shape
     pairs = _pair_list(tgt_img, ref_imgs, tgt_depths, ref_depths, poses, poses_inv)
     n = len(pairs)
@@ -442,12 +484,28 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         d.depth_shift = _pair_shift(dt, dr, B, H, W)
     lib.call(f"scsfm_pairs_bwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags, _p(scratch),
              _p(g_photo), _p(g_geom), _stream(tgt_img))
+    g_inputs = None
+    if need_imgs is not None or need_K:
+        # gradients of the data inputs (scsfm_pairs_bwd_inputs): images accumulate, intrinsics are stored
+        imgs = [tgt_img] + list(ref_imgs)
+        want = list(need_imgs) if need_imgs is not None else [False] * len(imgs)
+        g_imgs = [torch.zeros_like(im) if w else None for im, w in zip(imgs, want)]
+        g_K = torch.empty_like(K) if need_K else None
+        by_ptr = {im.data_ptr(): g for im, g in zip(imgs, g_imgs)}
+        for j, (ti, ri, *_rest) in enumerate(pairs):
+            descs[j].g_tgt_img = _p(by_ptr[ti.data_ptr()]) or None
+            descs[j].g_ref_img = _p(by_ptr[ri.data_ptr()]) or None
+        lib.call(f"scsfm_pairs_bwd_inputs_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags,
+                 _p(g_photo), _p(g_geom), _p(g_K), _stream(tgt_img))
+        g_inputs = (g_imgs, g_K)
     n_scales = len(tgt_depths)
     # pair j = 2 * (i * n_scales + s) + direction; a pose feeds every scale of its ref
     per = g_pose_all.view(len(ref_imgs), n_scales, 2, B, 6).sum(dim=1) if n_scales > 1 else \
         g_pose_all.view(len(ref_imgs), 2, B, 6)
     g_poses = [per[i, 0] for i in range(len(ref_imgs))]
     g_poses_inv = [per[i, 1] for i in range(len(ref_imgs))]
+    if g_inputs is not None:
+        return g_td, g_rd, g_poses, g_poses_inv, g_inputs[0], g_inputs[1]
     return g_td, g_rd, g_poses, g_poses_inv
 
 
@@ -495,6 +553,16 @@ def smooth_multi_bwd(lib, depths, imgs, ws, g_loss, need=None, into=None):
         grads = [g_all[i] if (need is None or need[i]) else None for i in range(n)]
     lib.call(f"scsfm_smooth_multi_bwd_{_suffix(imgs[0])}", n, _ptr_array(depths), _ptr_array(imgs), B, H, W, _p(ws),
              edges, _p(g_loss), _ptr_array(grads), 1 if into is not None else 0, _stream(imgs[0]))
+    return grads
+
+
+def smooth_multi_bwd_images(lib, depths, imgs, ws, g_loss, need):
+    """-> list of dL/d img (None where ``need[i]`` is False)."""
+    B, _, H, W = imgs[0].shape
+    n = len(depths)
+    grads = [torch.empty_like(imgs[i]) if need[i] else None for i in range(n)]
+    lib.call(f"scsfm_smooth_multi_bwd_images_{_suffix(imgs[0])}", n, _ptr_array(depths), _ptr_array(imgs), B, H, W,
+             _p(ws), _p(g_loss), _ptr_array(grads), 0, _stream(imgs[0]))
     return grads
 
 

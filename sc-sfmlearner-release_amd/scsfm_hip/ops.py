@@ -21,8 +21,9 @@ def _need_cuda(*ts):
 def _no_grad_inputs(ctx, first, names):
     for i, n in enumerate(names):
         if ctx.needs_input_grad[first + i]:
-            raise NotImplementedError(f"scsfm_hip: gradient with respect to `{n}` is not provided "
-                                      "(the reference never asks for it: images and intrinsics are data)")
+            raise NotImplementedError(f"scsfm_hip: compute_total_loss (an extension of this package) gives no gradient "
+                                      f"with respect to `{n}`; the reference-style calls -- "
+                                      "compute_photo_and_geometry_loss, compute_smooth_loss -- do")
 
 
 def _c(t):
@@ -44,7 +45,7 @@ class PhotoGeometryLoss(torch.autograd.Function):
 
     Depth maps are full resolution (scale s > 0 is nearest-upsampled by the caller, under
     autograd).  ref_depths is flattened ref-major: ref_depths[i * n_scales + s].
-    Gradients: every depth map and every pose; images and K are data.
+    Gradients: every depth map and every pose; images and K too when they require grad (train.py never asks).
     """
 
     @staticmethod
@@ -82,13 +83,19 @@ class PhotoGeometryLoss(torch.autograd.Function):
         n_ref, n_scales, flags = ctx.n_ref, ctx.n_scales, ctx.flags
         saved = ctx.saved_tensors
         tgt_img, K = saved[0], saved[1]
-        _no_grad_inputs(ctx, 3, ["tgt_img", "intrinsics"] + [f"ref_imgs[{i}]" for i in range(n_ref)])
         ref_imgs, tgt_depths, ref_depths, poses, poses_inv, n_in = PhotoGeometryLoss._split(saved[2:], n_ref, n_scales)
         ws = saved[2 + n_in]
-        g_td, g_rd, g_poses, g_poses_inv = capi.photo_geometry_bwd(
+        # images and intrinsics are data to train.py; the reference's autograd reaches them all the same, and so does
+        # this node when asked (one extra tiled pass for the images, a reduction for K)
+        need_imgs = [ctx.needs_input_grad[3]] + list(ctx.needs_input_grad[5:5 + n_ref])
+        need_K = ctx.needs_input_grad[4]
+        res = capi.photo_geometry_bwd(
             lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws,
-            _scalar(g_photo, tgt_img), _scalar(g_geom, tgt_img), hint_dev=ctx.hint_dev)
-        return (None, None, None, None, None, *([None] * n_ref), *g_td, *[g for r in g_rd for g in r], *g_poses,
+            _scalar(g_photo, tgt_img), _scalar(g_geom, tgt_img), hint_dev=ctx.hint_dev,
+            need_imgs=need_imgs if any(need_imgs) else None, need_K=need_K)
+        g_td, g_rd, g_poses, g_poses_inv = res[:4]
+        g_imgs, g_K = res[4:] if len(res) > 4 else ([None] * (1 + n_ref), None)
+        return (None, None, None, g_imgs[0], g_K, *g_imgs[1:], *g_td, *[g for r in g_rd for g in r], *g_poses,
                 *g_poses_inv)
 
 
@@ -110,11 +117,13 @@ class PairwiseLoss(torch.autograd.Function):
     def backward(ctx, g_photo, g_geom):
         lib = _lib.get()
         tgt_img, ref_img, tgt_depth, ref_depth, pose, K, ws = ctx.saved_tensors
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or ctx.needs_input_grad[6]:
-            raise NotImplementedError("scsfm_hip: no gradient for images / intrinsics")
-        g_td, g_rd, g_pose = capi.pair_bwd(lib, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, ctx.flags, ws,
-                                           _scalar(g_photo, tgt_img), _scalar(g_geom, tgt_img))
-        return None, None, None, g_td, g_rd, g_pose, None
+        need = ctx.needs_input_grad
+        res = capi.pair_bwd(lib, tgt_img, ref_img, tgt_depth, ref_depth, pose, K, ctx.flags, ws,
+                            _scalar(g_photo, tgt_img), _scalar(g_geom, tgt_img), need_tgt_img=need[1], need_ref_img=need[2],
+                            need_K=need[6])
+        g_td, g_rd, g_pose = res[:3]
+        g_ti, g_ri, g_K = res[3:] if len(res) > 3 else (None, None, None)
+        return None, g_ti, g_ri, g_td, g_rd, g_pose, g_K
 
 
 # ------------------------------------------------------------------------------------------------
@@ -141,10 +150,12 @@ class SmoothLoss(torch.autograd.Function):
         n = ctx.n
         saved = ctx.saved_tensors
         depths, imgs, ws = saved[:n], saved[n:2 * n], saved[2 * n]
-        if any(ctx.needs_input_grad[1 + n:]):
-            raise NotImplementedError("scsfm_hip: no gradient for images")
-        grads = capi.smooth_multi_bwd(lib, depths, imgs, ws, _scalar(g, imgs[0]), ctx.needs_input_grad[1:1 + n])
-        return (None, *grads, *([None] * n))
+        gs = _scalar(g, imgs[0])
+        grads = capi.smooth_multi_bwd(lib, depths, imgs, ws, gs, ctx.needs_input_grad[1:1 + n]) \
+            if any(ctx.needs_input_grad[1:1 + n]) else [None] * n
+        need_img = ctx.needs_input_grad[1 + n:]
+        g_imgs = capi.smooth_multi_bwd_images(lib, depths, imgs, ws, gs, need_img) if any(need_img) else [None] * n
+        return (None, *grads, *g_imgs)
 
 
 class StepLoss(torch.autograd.Function):
@@ -222,12 +233,12 @@ class InverseWarp2(torch.autograd.Function):
     def backward(ctx, g_img, g_valid, g_pd, g_cd):
         lib = _lib.get()
         img, depth, ref_depth, pose, K = ctx.saved_tensors
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[5]:
-            raise NotImplementedError("scsfm_hip: no gradient for the sampled image / intrinsics")
         cc = lambda t: None if t is None else t.contiguous()
-        g_depth, g_ref, g_pose = capi.warp_bwd(lib, img, depth, ref_depth, pose, K, ctx.flags, cc(g_img), cc(g_pd),
-                                               cc(g_cd))
-        return None, None, g_depth, g_ref, g_pose, None
+        res = capi.warp_bwd(lib, img, depth, ref_depth, pose, K, ctx.flags, cc(g_img), cc(g_pd), cc(g_cd),
+                            need_img=ctx.needs_input_grad[1], need_K=ctx.needs_input_grad[5])
+        g_depth, g_ref, g_pose = res[:3]
+        g_src, g_K = res[3:] if len(res) > 3 else (None, None)
+        return None, g_src, g_depth, g_ref, g_pose, g_K
 
 
 class Pixel2Cam(torch.autograd.Function):
@@ -237,14 +248,16 @@ class Pixel2Cam(torch.autograd.Function):
     def forward(ctx, depth, Kinv):
         depth, Kinv = _c(depth), _c(Kinv)
         _need_cuda(depth, Kinv)
-        ctx.save_for_backward(Kinv)
+        ctx.save_for_backward(Kinv, depth)
         return capi.pixel2cam_fwd(_lib.get(), depth, Kinv)
 
     @staticmethod
     def backward(ctx, g_cam):
-        _no_grad_inputs(ctx, 1, ["intrinsics_inv"])
-        (Kinv,) = ctx.saved_tensors
-        return capi.pixel2cam_bwd(_lib.get(), Kinv, g_cam.contiguous()), None
+        Kinv, depth = ctx.saved_tensors
+        g_cam = g_cam.contiguous()
+        g_depth = capi.pixel2cam_bwd(_lib.get(), Kinv, g_cam) if ctx.needs_input_grad[0] else None
+        g_kinv = capi.pixel2cam_bwd_intrinsics(_lib.get(), depth, g_cam) if ctx.needs_input_grad[1] else None
+        return g_depth, g_kinv
 
 
 class Cam2Pixel(torch.autograd.Function):
@@ -318,7 +331,7 @@ class SsimMap(torch.autograd.Function):
 
 
 class MaskedMean(torch.autograd.Function):
-    """mean_on_mask (loss_functions.py:123-129); the mask is treated as data."""
+    """mean_on_mask (loss_functions.py:123-129), with gradients to diff and -- when it requires grad -- to the mask."""
 
     @staticmethod
     def forward(ctx, diff, mask):
@@ -326,12 +339,14 @@ class MaskedMean(torch.autograd.Function):
         _need_cuda(diff, mask)
         out, ws = capi.masked_mean_fwd(_lib.get(), diff, mask)
         ctx.shape = diff.shape
-        ctx.save_for_backward(mask, ws)
+        ctx.save_for_backward(mask, ws, *([diff] if ctx.needs_input_grad[1] else []))
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
-        mask, ws = ctx.saved_tensors
-        if ctx.needs_input_grad[1]:
-            raise NotImplementedError("scsfm_hip: mean_on_mask treats the mask as data (no gradient)")
-        return capi.masked_mean_bwd(_lib.get(), ctx.shape, mask, ws, _scalar(g, mask)), None
+        mask, ws = ctx.saved_tensors[:2]
+        gs = _scalar(g, mask)
+        g_diff = capi.masked_mean_bwd(_lib.get(), ctx.shape, mask, ws, gs) if ctx.needs_input_grad[0] else None
+        g_mask = capi.masked_mean_bwd_mask(_lib.get(), ctx.saved_tensors[2], mask.shape, ws, gs) \
+            if ctx.needs_input_grad[1] else None
+        return g_diff, g_mask

@@ -27,6 +27,11 @@ EXPECTED = {
     "scsfm_masked_mean_fwd_f64", "scsfm_masked_mean_bwd_f64", "scsfm_augment_u8_f32",
     "scsfm_pixel2cam_fwd_f32", "scsfm_pixel2cam_bwd_f32", "scsfm_pixel2cam_fwd_f64", "scsfm_pixel2cam_bwd_f64",
     "scsfm_cam2pixel_fwd_f32", "scsfm_cam2pixel_bwd_f32", "scsfm_cam2pixel_fwd_f64", "scsfm_cam2pixel_bwd_f64",
+    # ABI 7: gradients of the data inputs (images, intrinsics, a floating-point mask)
+    "scsfm_pairs_bwd_inputs_f32", "scsfm_pairs_bwd_inputs_f64", "scsfm_warp_bwd_inputs_f32", "scsfm_warp_bwd_inputs_f64",
+    "scsfm_pixel2cam_bwd_intrinsics_f32", "scsfm_pixel2cam_bwd_intrinsics_f64",
+    "scsfm_masked_mean_bwd_mask_f32", "scsfm_masked_mean_bwd_mask_f64",
+    "scsfm_smooth_multi_bwd_images_f32", "scsfm_smooth_multi_bwd_images_f64",
 }
 
 
