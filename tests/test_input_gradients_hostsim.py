@@ -30,8 +30,14 @@ def _batch(B, H, W, seed, n_ref=2):
                 ps=[c(p) for p in d["poses"]], pis=[c(p) for p in d["poses_inv"]])
 
 
-@pytest.mark.parametrize("hint,upstream", [((0.7, 1.3), (0.7, 1.3)), ((1.0, 0.5), (0.3, 1.1)), (None, (0.7, 1.3))])
-@pytest.mark.parametrize("flags3,pad", [((1, 1, 1), "zeros"), ((1, 1, 0), "border"), ((0, 1, 1), "zeros"), ((1, 0, 0), "zeros")])
+@pytest.mark.parametrize("flags3,pad,hint,upstream", [
+    ((1, 1, 1), "zeros", (0.7, 1.3), (0.7, 1.3)),   # the speculative forward's planes stand
+    ((1, 1, 1), "zeros", (1.0, 0.5), (0.3, 1.1)),   # wrong hint: the backward ran its own passes
+    ((1, 1, 1), "zeros", None, (0.7, 1.3)),         # plain forward
+    ((1, 1, 0), "border", (0.7, 1.3), (0.7, 1.3)),
+    ((0, 1, 1), "zeros", (1.0, 0.5), (0.3, 1.1)),   # no SSIM
+    ((1, 0, 0), "zeros", None, (0.7, 1.3)),
+])
 def test_photo_geometry_gradients_of_images_and_intrinsics(lib, flags3, pad, hint, upstream):
     """Both after a speculative forward whose planes stand, after one whose hint was wrong (the backward's own
     passes), and after the plain forward."""

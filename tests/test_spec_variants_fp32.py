@@ -17,7 +17,7 @@ CASES = [  # B, H, W, depth, padding (the 10000-pixel gates are open in every ca
     (4, 72, 100, "smooth", "zeros"),
     (4, 72, 100, "iid", "zeros"),      # landing positions spread over more than a window: nothing is staged
     (4, 72, 100, "smooth", "border"),  # (runtime-flag instantiation)
-    (40, 15, 63, "smooth", "zeros"),   # lower than the staged window and narrower: clamped rows / columns
+    (24, 15, 63, "smooth", "zeros"),   # lower than the staged window and narrower: clamped rows / columns
     (5, 41, 150, "smooth", "zeros"),   # partial tiles in both directions
 ]
 
