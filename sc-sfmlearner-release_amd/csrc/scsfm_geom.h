@@ -492,7 +492,24 @@ __device__ __forceinline__ bool win_fits(const double*, double) { return true; }
 __device__ __forceinline__ bool win_fits(const float*, float) { return true; }
 template <typename T> struct WinCell { typedef int type; };
 template <> struct WinCell<double> { typedef double type; };
-__device__ __forceinline__ void win_add(int* p, float v) { lds_add(p, (int)t_floor(v * kFixScale + 0.5f)); }
+// floor(x + 0.5) as an integer: ONE instruction on gfx950 (v_cvt_rpi_i32_f32, "round to plus infinity on ties") instead
+// of add, floor, convert -- the window takes 16 of these per thread
+__device__ __forceinline__ int cvt_round_half_up(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+#else
+  return (int)floorf(x + 0.5f);
+#endif
+}
+// A value in the unit a cell counts in (the power-of-two scale is exact, so it is applied to the pixel's gradient once
+// instead of to each of its four weighted taps) ...
+__device__ __forceinline__ float win_unit(const int*, float g) { return g * kFixScale; }
+__device__ __forceinline__ double win_unit(const double*, double g) { return g; }
+__device__ __forceinline__ float win_unit(const float*, float g) { return g; }
+// ... added to a cell
+__device__ __forceinline__ void win_add(int* p, float units) { lds_add(p, cvt_round_half_up(units)); }
 __device__ __forceinline__ void win_add(double* p, double v) { lds_add(p, v); }
 __device__ __forceinline__ void win_add(float* p, float v) { lds_add(p, v); }  // (float cells: see geom_tile)
 __device__ __forceinline__ float win_value(int c) { return float(c) * kFixInv; }
@@ -506,10 +523,11 @@ __device__ __forceinline__ void scatter_taps_window(Cell (*win)[WW], int wx0, in
   const int lx = s.xa - wx0, ly = s.ya - wy0;
   if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < WH - 1 && win_fits(&win[0][0], g)) {
     // unpredicated: a cell of the block that is not a tap has weight 0, and adding 0 leaves it at the 0 the flush skips
-    win_add(&win[ly][lx], g * s.wp[0]);
-    win_add(&win[ly][lx + 1], g * s.wp[1]);
-    win_add(&win[ly + 1][lx], g * s.wp[2]);
-    win_add(&win[ly + 1][lx + 1], g * s.wp[3]);
+    const T gu = win_unit(&win[0][0], g);
+    win_add(&win[ly][lx], gu * s.wp[0]);
+    win_add(&win[ly][lx + 1], gu * s.wp[1]);
+    win_add(&win[ly + 1][lx], gu * s.wp[2]);
+    win_add(&win[ly + 1][lx + 1], gu * s.wp[3]);
   } else {
     scatter_taps(gplane, s, g);
   }
