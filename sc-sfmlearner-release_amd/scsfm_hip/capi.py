@@ -556,13 +556,16 @@ def smooth_multi_bwd(lib, depths, imgs, ws, g_loss, need=None, into=None):
     return grads
 
 
-def smooth_multi_bwd_images(lib, depths, imgs, ws, g_loss, need):
-    """-> list of dL/d img (None where ``need[i]`` is False)."""
+def smooth_multi_bwd_images(lib, depths, imgs, ws, g_loss, need, into=None):
+    """-> list of dL/d img (None where ``need[i]`` is False).  ``into``: existing buffers the gradient is ADDED to."""
     B, _, H, W = imgs[0].shape
     n = len(depths)
-    grads = [torch.empty_like(imgs[i]) if need[i] else None for i in range(n)]
+    if into is not None:
+        grads = [into[i] if need[i] else None for i in range(n)]
+    else:
+        grads = [torch.empty_like(imgs[i]) if need[i] else None for i in range(n)]
     lib.call(f"scsfm_smooth_multi_bwd_images_{_suffix(imgs[0])}", n, _ptr_array(depths), _ptr_array(imgs), B, H, W,
-             _p(ws), _p(g_loss), _ptr_array(grads), 0, _stream(imgs[0]))
+             _p(ws), _p(g_loss), _ptr_array(grads), 1 if into is not None else 0, _stream(imgs[0]))
     return grads
 
 

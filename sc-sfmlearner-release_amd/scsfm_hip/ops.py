@@ -18,14 +18,6 @@ def _need_cuda(*ts):
                                "this package has no CPU fallback")
 
 
-def _no_grad_inputs(ctx, first, names):
-    for i, n in enumerate(names):
-        if ctx.needs_input_grad[first + i]:
-            raise NotImplementedError(f"scsfm_hip: compute_total_loss (an extension of this package) gives no gradient "
-                                      f"with respect to `{n}`; the reference-style calls -- "
-                                      "compute_photo_and_geometry_loss, compute_smooth_loss -- do")
-
-
 def _c(t):
     return t.contiguous()
 
@@ -199,15 +191,21 @@ class StepLoss(torch.autograd.Function):
         flags, n_ref, n_scales, w_photo, w_smooth, w_geom = ctx.cfg
         saved = ctx.saved_tensors
         tgt_img, K = saved[0], saved[1]
-        _no_grad_inputs(ctx, 6, ["tgt_img", "intrinsics"] + [f"ref_imgs[{i}]" for i in range(n_ref)])
         ref_imgs, tgt_depths, ref_depths, poses, poses_inv, n_in = PhotoGeometryLoss._split(saved[2:], n_ref, n_scales)
         ws, sws = saved[2 + n_in], saved[3 + n_in]
         gw = capi.step_weights(lib, _scalar(g_loss, tgt_img), w_photo, w_smooth, w_geom)
-        g_td, g_rd, g_poses, g_poses_inv = capi.photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths,
-                                                                  ref_depths, poses, poses_inv, ws, gw[0:1], gw[1:2])
+        need_imgs = [ctx.needs_input_grad[6]] + list(ctx.needs_input_grad[8:8 + n_ref])
+        need_K = ctx.needs_input_grad[7]
+        res = capi.photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws,
+                                      gw[0:1], gw[1:2], need_imgs=need_imgs if any(need_imgs) else None, need_K=need_K)
+        g_td, g_rd, g_poses, g_poses_inv = res[:4]
+        g_imgs, g_K = res[4:] if len(res) > 4 else ([None] * (1 + n_ref), None)
         frames = [tgt_depths[0]] + [r[0] for r in ref_depths]
-        capi.smooth_multi_bwd(lib, frames, [tgt_img] + list(ref_imgs), sws, gw[2:3], into=[g_td[0]] + [r[0] for r in g_rd])
-        return (None,) * 6 + (None, None) + (None,) * n_ref + (*g_td, *[g for r in g_rd for g in r], *g_poses, *g_poses_inv)
+        imgs = [tgt_img] + list(ref_imgs)
+        capi.smooth_multi_bwd(lib, frames, imgs, sws, gw[2:3], into=[g_td[0]] + [r[0] for r in g_rd])
+        if any(need_imgs):  # (the data inputs: the smooth term reaches the images through its edge weights)
+            capi.smooth_multi_bwd_images(lib, frames, imgs, sws, gw[2:3], need_imgs, into=g_imgs)
+        return (None,) * 6 + (g_imgs[0], g_K, *g_imgs[1:], *g_td, *[g for r in g_rd for g in r], *g_poses, *g_poses_inv)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -149,3 +149,20 @@ def test_pixel2cam_mean_on_mask_and_smooth_loss_reach_their_data_inputs(dev):
     LF.compute_smooth_loss(g["tds"], g["ti"], g["rds"], g["ris"]).backward()
     assert _rel(g["ti"].grad, o["ti"].grad) < 1e-10 and _rel(g["ris"][1].grad, o["ris"][1].grad) < 1e-10
     assert _rel(g["tds"][0].grad, o["tds"][0].grad) < 1e-10
+
+
+def test_single_node_step_gives_the_same_input_gradients_as_the_three_calls(dev):
+    """compute_total_loss (this package's extension: both losses and the weighted sum behind one autograd node) against
+    compute_photo_and_geometry_loss + compute_smooth_loss + the weighted sum, fp64."""
+    import loss_functions as LF
+    x = _make(4, 72, 100, 33, torch.float64)
+    a, b = _leaves(x, dev), _leaves(x, dev)
+    w = (0.9, 0.2, 0.6)
+    p, g = LF.compute_photo_and_geometry_loss(a["ti"], a["ris"], a["K"], a["tds"], a["rds"], a["ps"], a["pis"], 1, 1, 1, 1, "zeros")
+    s = LF.compute_smooth_loss(a["tds"], a["ti"], a["rds"], a["ris"])
+    (w[0] * p + w[1] * s + w[2] * g).backward()
+    loss = LF.compute_total_loss(b["ti"], b["ris"], b["K"], b["tds"], b["rds"], b["ps"], b["pis"], 1, 1, 1, 1, "zeros", *w)[0]
+    loss.backward()
+    pairs = [(a["ti"], b["ti"]), (a["K"], b["K"]), (a["tds"][0], b["tds"][0]), (a["ps"][1], b["ps"][1])] + list(zip(a["ris"], b["ris"]))
+    for u, v in pairs:
+        assert _rel(v.grad, u.grad.cpu()) < 1e-10
