@@ -756,7 +756,8 @@ struct CombineBatch {
   int store[2 * kMaxPairs];  // 1: dst = sum (the first time a call touches this buffer), 0: dst += sum
   int ds[2 * kMaxPairs];     // dst is the gradient of a [H >> ds, W >> ds] map: the planes are sum-pooled into it
   int nd, nsrc;
-  CombineSrc<T> src[2 * kMaxPairs];
+  CombineSrc<T> src[2 * kMaxPairs];  // sorted by dst: the sources of dst d are src[first[d] .. first[d] + count[d])
+  int first[2 * kMaxPairs], count[2 * kMaxPairs];
 };
 
 template <typename T>
@@ -781,6 +782,65 @@ __device__ __forceinline__ bool combine_sources(const CombineBatch<T>& cb, int d
     }
   }
   return aligned;
+}
+
+// The 16-byte part of one destination with exactly NS sources, all loads of a thread's (up to) two quads issued before
+// the first is used.  A source whose pair is not live (both upstream coefficients zero: its planes may never have been
+// written) is replaced by a live one with weight 0, so that no load sits behind a branch; returns false (nothing done)
+// when no source is live and the general loop should store the zeros.
+template <typename T, int NS>
+__device__ __forceinline__ bool combine_quads(const CombineBatch<T>& cb, int d, size_t nq, bool store,
+                                              const T* __restrict__ g_photo, const T* __restrict__ g_geom) {
+  constexpr int Q = 16 / sizeof(T);
+  const Quad<T>* p[NS];
+  T sc[NS];
+  const Quad<T>* safe = nullptr;
+  const int f = cb.first[d];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const CombineSrc<T>& c = cb.src[f + j];
+    const bool live = !(T(c.sums[5]) * g_photo[0] == T(0) && T(c.sums[6]) * g_geom[0] == T(0));
+    sc[j] = live ? pair_scale(c.sums, g_photo, g_geom) : T(0);
+    p[j] = reinterpret_cast<const Quad<T>*>(c.plane);
+    if (sc[j] != T(0) && !safe) safe = p[j];
+  }
+  if (!safe) return false;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) p[j] = sc[j] != T(0) ? p[j] : safe;
+  Quad<T>* __restrict__ out = reinterpret_cast<Quad<T>*>(cb.dst[d]);
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  for (; i + stride < nq; i += 2 * stride) {
+    Quad<T> x[2][NS], o[2];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) { x[0][j] = p[j][i]; x[1][j] = p[j][i + stride]; }
+    if (!store) { o[0] = out[i]; o[1] = out[i + stride]; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      Quad<T> acc;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) acc.v[q] = store ? T(0) : o[h].v[q];
+#pragma unroll
+      for (int j = 0; j < NS; ++j)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc.v[q] += sc[j] * x[h][j].v[q];
+      out[i + h * stride] = acc;
+    }
+  }
+  for (; i < nq; i += stride) {
+    Quad<T> acc;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc.v[q] = T(0);
+    if (!store) acc = out[i];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const Quad<T> x = p[j][i];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) acc.v[q] += sc[j] * x.v[q];
+    }
+    out[i] = acc;
+  }
+  return true;
 }
 
 template <typename T>
@@ -816,7 +876,17 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
   // 16-byte accesses over the part every plane has 16-byte aligned (n is a multiple of Q for every image size
   // in use; the scalar loop below takes whatever is left)
   const size_t nq = aligned ? n / Q : 0;
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nq; i += (size_t)gridDim.x * kThreads) {
+  // The usual shapes -- a map with 2 .. 4 sources (the dense plane of the pairs it is the target of, the scatter plane
+  // of those that sampled it) -- run with every load of a thread's two quads in flight together (combine_quads);
+  // anything else takes the general loop.
+  bool done = false;
+  switch (cb.count[d]) {
+    case 2: done = combine_quads<T, 2>(cb, d, nq, store, g_photo, g_geom); break;
+    case 3: done = combine_quads<T, 3>(cb, d, nq, store, g_photo, g_geom); break;
+    case 4: done = combine_quads<T, 4>(cb, d, nq, store, g_photo, g_geom); break;
+    default: break;
+  }
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; !done && i < nq; i += (size_t)gridDim.x * kThreads) {
     Quad<T> acc;
 #pragma unroll
     for (int j = 0; j < Q; ++j) acc.v[j] = T(0);
@@ -885,15 +955,27 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_pooled_kernel(CombineB
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pairs_zero_prep_kernel(PairBatch<T> pb, size_t n, int npairs, int B,
                                                                    const T* __restrict__ K) {
-  if (blockIdx.x == 0 && blockIdx.y == 0) {
-    if (threadIdx.x == 0) *finalize_counter(pb) = 0u;
-    for (int i = threadIdx.x; i < npairs * B; i += kThreads) {
-      const int pair = i / B, b = i - pair * B;
-      prep_one(b, pb.p[pair].pose, K, pb.p[pair].consts);
+  // the last column of workgroups does not clear anything: its first one derives the per-image constants (a chain of
+  // sincos / reciprocal latencies that would otherwise sit in front of one workgroup's share of the stream)
+  if (blockIdx.x == gridDim.x - 1) {
+    if (blockIdx.y == 0) {
+      if (threadIdx.x == 0) *finalize_counter(pb) = 0u;
+      for (int i = threadIdx.x; i < npairs * B; i += kThreads) {
+        const int pair = i / B, b = i - pair * B;
+        prep_one(b, pb.p[pair].pose, K, pb.p[pair].consts);
+      }
     }
+    return;
   }
   T* __restrict__ p = pb.p[blockIdx.y].gbuf + kPlaneScatter * n;
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) p[i] = T(0);
+  constexpr int Q = 16 / sizeof(T);
+  const size_t stride = (size_t)(gridDim.x - 1) * kThreads, t0 = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  const size_t nq = (reinterpret_cast<size_t>(p) & 15) == 0 ? n / Q : 0;  // 16-byte stores where the plane allows
+  Quad<T> z;
+#pragma unroll
+  for (int j = 0; j < Q; ++j) z.v[j] = T(0);
+  for (size_t i = t0; i < nq; i += stride) reinterpret_cast<Quad<T>*>(p)[i] = z;
+  for (size_t i = nq * Q + t0; i < n; i += stride) p[i] = T(0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1000,7 +1082,7 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
   if (spec) {
     const size_t npx = (size_t)B * H * W;
     if (!kernel_only)
-      hipLaunchKernelGGL((pairs_zero_prep_kernel<T>), dim3(1024, n), dim3(kThreads), 0, stream, pb, npx, n, B, K);
+      hipLaunchKernelGGL((pairs_zero_prep_kernel<T>), dim3(1024 + 1, n), dim3(kThreads), 0, stream, pb, npx, n, B, K);
     const T r_hint = w_photo != 0.0 ? T(3.0 * w_geom / w_photo) : T(0);
     const bool timed = g_profile.used < g_profile.n;
     if (timed) (void)hipEventRecord(g_profile.start[g_profile.used], stream);
@@ -1150,6 +1232,18 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
           sc.sums = pb.p[i].sums;
           sc.dst = k;
         }
+      }
+      {  // the sources of one destination side by side (stable: pair order is kept within a destination)
+        CombineSrc<T> sorted[2 * kMaxPairs];
+        int ns = 0;
+        for (int k = 0; k < cb.nd; ++k) {
+          cb.first[k] = ns;
+          for (int q = 0; q < cb.nsrc; ++q)
+            if (cb.src[q].dst == k) sorted[ns++] = cb.src[q];
+          cb.count[k] = ns - cb.first[k];
+        }
+        for (int q = 0; q < cb.nsrc; ++q) cb.src[q] = sorted[q];
+        for (int k = cb.nd; k < 2 * kMaxPairs; ++k) { cb.first[k] = 0; cb.count[k] = 0; }
       }
       int gx = (int)((npx + 8 * kThreads - 1) / (8 * kThreads));
       const int gpose = ceil_div(m * B, kThreads / kWave);

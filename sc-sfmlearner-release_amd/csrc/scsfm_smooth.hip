@@ -20,7 +20,10 @@ namespace scsfm {
 #define SCSFM_SMOOTH_ROWS 4
 #endif
 constexpr int kSmRows = SCSFM_SMOOTH_ROWS;  // rows per thread (backward)
-constexpr int kSmFwdRows = 8;                // rows per thread of the forward
+#ifndef SCSFM_SMOOTH_FWD_ROWS  // tuning knob
+#define SCSFM_SMOOTH_FWD_ROWS 8
+#endif
+constexpr int kSmFwdRows = SCSFM_SMOOTH_FWD_ROWS;  // rows per thread of the forward
 constexpr int kSmFwdCols = kWave - 2;        // owned columns per wave of the forward (lanes 1 .. 62; 0 and 63 are halo)
 constexpr int kMaxFrames = 8;
 
@@ -202,17 +205,25 @@ __global__ __launch_bounds__(kThreads) void smooth_bwd_kernel(SmoothBatch<T> sb,
   const T iden = T(1.0 / fr.per_img[2 * b]);
   const T icx = T(1.0 / ((double)B * H * (W - 1))), icy = T(1.0 / ((double)B * (H - 1) * W));
   const T mean_term = T(fr.per_img[2 * b + 1] / (fr.per_img[2 * b] * fr.per_img[2 * b] * (double)H * W));
-  if (fr.edge) {  // the forward left the per-pixel edge terms: 4 B read + 4 B written per pixel
+  if (fr.edge) {  // the forward left the per-pixel edge terms: 4 B read + 4 B written per pixel, as a linear 16-byte stream
     const T* __restrict__ edge = fr.edge + (size_t)b * plane;
-    if (in_x) {
+    constexpr int Q = 16 / sizeof(T);
+    struct alignas(16) Quad { T v[Q]; };
+    const unsigned nthreads = gridDim.x * gridDim.y * kThreads;
+    const unsigned tid = (blockIdx.y * gridDim.x + blockIdx.x) * kThreads + threadIdx.x;
+    const bool aligned = ((reinterpret_cast<size_t>(edge) | reinterpret_cast<size_t>(g_depth)) & 15) == 0;
+    const unsigned nq = aligned ? plane / Q : 0;
+    for (unsigned q = tid; q < nq; q += nthreads) {
+      const Quad e = reinterpret_cast<const Quad*>(edge)[q];
+      Quad o;
+      if (kAccumulate) o = reinterpret_cast<const Quad*>(g_depth)[q];
 #pragma unroll
-      for (int r = 0; r < kSmRows; ++r) {
-        const int y = y0 + r;
-        if (y >= H) break;
-        const unsigned off = (unsigned(y) * unsigned(W) + unsigned(x)) * unsigned(sizeof(T));
-        const T v = g * (ld_at(edge, off) * iden - mean_term);
-        st_at(g_depth, off, kAccumulate ? ld_at(g_depth, off) + v : v);
-      }
+      for (int j = 0; j < Q; ++j) o.v[j] = (kAccumulate ? o.v[j] : T(0)) + g * (e.v[j] * iden - mean_term);
+      reinterpret_cast<Quad*>(g_depth)[q] = o;
+    }
+    for (unsigned i = nq * Q + tid; i < plane; i += nthreads) {
+      const T v = g * (edge[i] * iden - mean_term);
+      g_depth[i] = kAccumulate ? g_depth[i] + v : v;
     }
     return;
   }
