@@ -42,7 +42,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy rate
 W_PHOTO, W_SMOOTH, W_GEOM = 1.0, 0.1, 0.5  # train.py:45-47 defaults used by scripts/train_resnet18_depth_256.sh
-DOMINANT_KERNEL = "pair_fwd_spec_kernel<float,true,7u,false>"
+DOMINANT_KERNEL = "pair_fwd_spec_kernel<float,true,7u,false,false>"
 
 
 def log(*a):
