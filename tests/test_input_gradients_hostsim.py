@@ -139,3 +139,25 @@ def test_smooth_loss_gradient_of_the_images(lib):
     got = capi.smooth_multi_bwd_images(lib, depths, raw, ws, torch.tensor([2.5], dtype=torch.float64), [True, False, True])
     assert got[1] is None
     assert _rel(got[0], imgs[0].grad) < 1e-11 and _rel(got[2], imgs[2].grad) < 1e-11
+
+
+def test_two_scales_read_in_place_give_the_same_input_gradients(lib):
+    """A coarser scale's maps go to the library as they are (scsfm_pair_desc::depth_shift): the image pass and the
+    intrinsics reduction run over all 2 x n_ref x n_scales pair-directions."""
+    d = synth.make_batch(7, 40, 92, n_ref=2, seed=12, depth="smooth", num_scales=2)
+    c = lambda t: t.double().contiguous()
+    ti, K, ris = c(d["tgt_img"]), c(d["intrinsics"]), [c(r) for r in d["ref_imgs"]]
+    tds, rds = [c(t) for t in d["tgt_depth"]], [[c(t) for t in r] for r in d["ref_depths"]]
+    ps, pis = [c(p) for p in d["poses"]], [c(p) for p in d["poses_inv"]]
+    lti, lK, lris = leaf(ti), leaf(K), [leaf(r) for r in ris]
+    po, go = O.photo_and_geometry_loss(lti, lris, lK, tds, rds, ps, pis, 2, 1, 1, 1, "zeros")
+    (po + 0.5 * go).backward()
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    photo, geom, _, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=(1.0, 0.5))
+    assert abs(float(photo) - float(po)) < 1e-11
+    t = lambda v: torch.tensor([v], dtype=torch.float64)
+    res = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, t(1.0), t(0.5), need_imgs=[True, True, True],
+                                  need_K=True)
+    assert _rel(res[5], lK.grad) < 1e-9 and _rel(res[4][0], lti.grad) < 1e-10
+    for i in range(2):
+        assert _rel(res[4][1 + i], lris[i].grad) < 1e-10
