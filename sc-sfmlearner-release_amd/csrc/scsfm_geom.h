@@ -354,6 +354,69 @@ __device__ __forceinline__ TapRows<T> load_tap_rows(const T* __restrict__ plane,
   r.s = ld_at(reinterpret_cast<const TapPair<T>*>(plane), s.offr[1] * unsigned(sizeof(T)));
   return r;
 }
+// The three colour planes of one image of the batch behind ONE buffer resource (gfx950: buffer_load ... s[rsrc], soffset
+// offen): the plane's offset travels in the instruction's SCALAR offset operand, the lane's 32-bit byte offset in its
+// vector operand.  With a base pointer per plane the compiler, short of scalar registers in the speculative forward,
+// formed 64-bit vector addresses (v_lshl_add_u64, half rate) for most of that kernel's image loads.  The host build
+// of the CPU simulation reads through the pointer.
+template <typename T>
+struct Planes3 {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t r;
+#else
+  const T* p;
+#endif
+  unsigned pb;  // bytes per plane
+};
+template <typename T>
+__device__ __forceinline__ Planes3<T> planes3(const T* __restrict__ base, unsigned plane) {
+  Planes3<T> q;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // raw buffer, no stride, no bounds (every offset is formed from in-image coordinates); dword 3 as for gfx90a / gfx94x
+  q.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, 0xffffffffu, 0x00020000);
+#else
+  q.p = base;
+#endif
+  q.pb = plane * unsigned(sizeof(T));
+  return q;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ TapPair<float> buf_ld_pair(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float) {
+  return __builtin_bit_cast(TapPair<float>, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ TapPair<double> buf_ld_pair(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double) {
+  return __builtin_bit_cast(TapPair<double>, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+#endif
+// plane c at byte offset `off` inside a plane
+template <typename T>
+__device__ __forceinline__ T ld_plane(const Planes3<T>& q, int c, unsigned off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return buf_ld(q.r, off, unsigned(c) * q.pb, T());
+#else
+  return ld_at(q.p, off + unsigned(c) * q.pb);
+#endif
+}
+// the 2 x 2 block of a sample in plane c
+template <typename T>
+__device__ __forceinline__ TapRows<T> load_tap_rows(const Planes3<T>& q, int c, const Sample<T>& s) {
+  TapRows<T> r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  r.n = buf_ld_pair(q.r, s.offr[0] * unsigned(sizeof(T)), unsigned(c) * q.pb, T());
+  r.s = buf_ld_pair(q.r, s.offr[1] * unsigned(sizeof(T)), unsigned(c) * q.pb, T());
+#else
+  r.n = ld_at(reinterpret_cast<const TapPair<T>*>(q.p), s.offr[0] * unsigned(sizeof(T)) + unsigned(c) * q.pb);
+  r.s = ld_at(reinterpret_cast<const TapPair<T>*>(q.p), s.offr[1] * unsigned(sizeof(T)) + unsigned(c) * q.pb);
+#endif
+  return r;
+}
+
 // A depth map as the pair kernels read it.  Full resolution: the [H, W] plane.  kScaled (kernels instantiated for
 // multi-scale steps): the map of a coarser scale, [H >> ds, W >> ds], whose nearest up-sampling to (H, W)
 // (loss_functions.py:77-82: F.interpolate(..., mode='nearest') of every scale before compute_pairwise_loss) is
@@ -619,7 +682,7 @@ struct StagedTaps {
 // kRows: rows of the staged window; kDepth: the depth plane is staged too (else it is gathered).
 template <int kRows, bool kDepth, typename T, typename Map>
 __device__ __forceinline__ GeomTaps<T> geom_fetch(const BatchConsts<T>& bc, int px, int py, T d,
-                                                  const T* __restrict__ ref_img, const Map& ref_depth, unsigned plane,
+                                                  const Planes3<T>& ref_img, const Map& ref_depth,
                                                   int H, int W, unsigned flags, const StagedTaps<T>& st) {
   GeomTaps<T> f;
   f.s = project_pixel(bc, px, py, d, H, W, flags);
@@ -638,7 +701,7 @@ __device__ __forceinline__ GeomTaps<T> geom_fetch(const BatchConsts<T>& bc, int 
     }
   } else {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) f.tc[c] = load_tap_rows(ref_img + c * plane, f.s);
+    for (int c = 0; c < 3; ++c) f.tc[c] = load_tap_rows(ref_img, c, f.s);
     if (kDepth) f.td = ref_depth.taps(f.s);
   }
   return f;

@@ -89,6 +89,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
   const size_t gplane = (size_t)B * plane;  // one gbuf plane spans the whole batch
   tgt_img += (size_t)b * 3 * plane;
   ref_img += (size_t)b * 3 * plane;
+  const Planes3<T> tgtP = planes3(tgt_img, plane), refP = planes3(ref_img, plane);
   const DepthMap<T, kScaled> tgt_depth = depth_map<kScaled>(pa.tgt_depth, b, H, W, pa.ds);
   const DepthMap<T, kScaled> ref_depth = depth_map<kScaled>(pa.ref_depth, b, H, W, pa.ds);
   gbuf += (size_t)b * plane;
@@ -275,17 +276,30 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
   } else {
     // ---- phase 0: every streaming load of the strip and of this thread's ring pixel ---------------
     const int u = reflect_index(px, W);
-    T in_t[STRIP][3], in_r[STRIP][3], rin_d = T(0), rin_t[3] = {T(0), T(0), T(0)}, rin_r[3];
+    T in_t[STRIP][3], in_r[STRIP][3], rin_d = T(0), rin_t[3] = {T(0), T(0), T(0)};
   #pragma unroll
-    for (int k = 0; k < STRIP; ++k)
-      load_pixel(u, reflect_index(py0 + k, H), W, plane, tgt_img, ref_img, tgt_depth, with_auto, in_d[k], in_t[k],
-                 in_r[k]);
+    for (int k = 0; k < STRIP; ++k) {
+      const int v = reflect_index(py0 + k, H);
+      const unsigned off = (unsigned(v) * unsigned(W) + unsigned(u)) * unsigned(sizeof(T));
+      in_d[k] = tgt_depth.at(u, v, off);
+  #pragma unroll
+      for (int c = 0; c < 3; ++c) in_t[k][c] = ld_plane(tgtP, c, off);
+  #pragma unroll
+      for (int c = 0; c < 3; ++c) in_r[k][c] = T(0);
+      if (with_auto) {
+  #pragma unroll
+        for (int c = 0; c < 3; ++c) in_r[k][c] = ld_plane(refP, c, off);
+      }
+    }
     const bool has_ring = kSsim && threadIdx.x < 2 * kHaloW + 2 * TH;
     int ru = 0, rv = 0, rhy = 0, rhx = 0;
     if (has_ring) {
       ring_pos<TH>(threadIdx.x, rhy, rhx);
       ru = reflect_index(ox + rhx - 1, W); rv = reflect_index(oy + rhy - 1, H);
-      load_pixel(ru, rv, W, plane, tgt_img, ref_img, tgt_depth, false, rin_d, rin_t, rin_r);
+      const unsigned off = (unsigned(rv) * unsigned(W) + unsigned(ru)) * unsigned(sizeof(T));
+      rin_d = tgt_depth.at(ru, rv, off);
+  #pragma unroll
+      for (int c = 0; c < 3; ++c) rin_t[c] = ld_plane(tgtP, c, off);
     }
     // ---- phase 1a ------------------------------------------------------------------------------
     // SCSFM_W_GROUP pixels' gathers are in flight together (tools/march_timing.py: with one pixel after the other this
@@ -303,7 +317,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
         const int k = k0 + j;
         sm[j] = project_pixel(bc, u, reflect_index(py0 + k, H), in_d[k], H, W, flags);
   #pragma unroll
-        for (int c = 0; c < 3; ++c) tc[j][c] = load_tap_rows(ref_img + c * plane, sm[j]);
+        for (int c = 0; c < 3; ++c) tc[j][c] = load_tap_rows(refP, c, sm[j]);
         td[j] = ref_depth.taps(sm[j]);
       }
       if (WG_ > 1) sched_fence();
@@ -348,10 +362,9 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     // ---- phase 1b: ring ------------------------------------------------------------------------
     if constexpr (kSsim) {
       if (has_ring) {
-        V2 xy[3];
-        warp_colours(bc, ru, rv, rin_d, rin_t, H, W, flags, ref_img, xy);
+        const Sample<T> rs = project_pixel(bc, ru, rv, rin_d, H, W, flags);
   #pragma unroll
-        for (int c = 0; c < 3; ++c) sXY[c][rhy][rhx] = xy[c];
+        for (int c = 0; c < 3; ++c) sXY[c][rhy][rhx] = make2(rin_t[c], bilerp_rows(load_tap_rows(refP, c, rs), rs));
       }
       STAMP(2);
       __syncthreads();
@@ -418,7 +431,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
         for (int c = 0; c < 4; ++c) stage_v[c][i] = T(0); \
         if (on) { \
   _Pragma("unroll") \
-          for (int c = 0; c < 3; ++c) stage_v[c][i] = ld_at(ref_img + c * plane, off); \
+          for (int c = 0; c < 3; ++c) stage_v[c][i] = ld_plane(refP, c, off); \
           if (!kLean) stage_v[3][i] = ref_depth.at(x, y, off); \
         } \
       } \
@@ -557,7 +570,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
         if constexpr (kSsim) gI[c] = reinterpret_cast<const T*>(&sXY[c][0][0])[(lrow + k) * kTileW + col]; else gI[c] = gI_reg[k][c];
       }
       if constexpr (kStage) {
-        const GeomTaps<T> f = geom_fetch<kStageRows, !kLean>(bc, px, py, d_own[k], ref_img, ref_depth, plane, H, W, flags, staged);
+        const GeomTaps<T> f = geom_fetch<kStageRows, !kLean>(bc, px, py, d_own[k], refP, ref_depth, H, W, flags, staged);
         gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, d_own[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc);
       } else {
         gd[k] = geom_pixel<T, Cell, WW, WH>(bc, px, py, d_own[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
