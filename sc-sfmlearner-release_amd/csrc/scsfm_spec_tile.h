@@ -303,9 +303,10 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     }
     // ---- phase 1a ------------------------------------------------------------------------------
     // SCSFM_W_GROUP pixels' gathers are in flight together (tools/march_timing.py: with one pixel after the other this
-    // phase took 12,400 of a tile's 48,000 cycles, a third of it vector instructions)
+    // phase took 12,400 of a tile's 48,000 cycles, a third of it vector instructions).  2 since the image loads are
+    // buffer loads: -1.6 % (323 against 328 us per launch, three alternating runs each); 4 spills 12 registers.
   #ifndef SCSFM_W_GROUP
-  #define SCSFM_W_GROUP 1
+  #define SCSFM_W_GROUP 2
   #endif
     constexpr int WG_ = SCSFM_W_GROUP < STRIP ? SCSFM_W_GROUP : STRIP;
   #pragma unroll
