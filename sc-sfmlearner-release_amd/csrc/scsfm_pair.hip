@@ -75,6 +75,22 @@ __device__ __forceinline__ void load_pixel(int u, int v, int W, unsigned plane, 
   }
 }
 
+// ... through one buffer resource per image (Planes3, scsfm_geom.h)
+template <typename T, typename Map>
+__device__ __forceinline__ void load_pixel(int u, int v, int W, const Planes3<T>& tgt_img, const Planes3<T>& ref_img,
+                                           const Map& tgt_depth, bool with_ref, T& depth, T (&tgt)[3], T (&ref)[3]) {
+  const unsigned off = (unsigned(v) * unsigned(W) + unsigned(u)) * unsigned(sizeof(T));
+  depth = tgt_depth.at(u, v, off);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) tgt[c] = ld_plane(tgt_img, c, off);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ref[c] = T(0);
+  if (with_ref) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ref[c] = ld_plane(ref_img, c, off);
+  }
+}
+
 // Warp one pixel: the (target, warped) colour pairs.
 template <typename T>
 __device__ __forceinline__ Sample<T> warp_colours(const BatchConsts<T>& bc, int u, int v, T depth, const T (&tgt)[3],
@@ -122,8 +138,14 @@ __device__ __forceinline__ T pixel_mask(const Sample<T>& s, bool with_auto, cons
 // ==========================================================================================
 // Forward
 // ==========================================================================================
+#ifndef SCSFM_FWD_BLOCKS  // tuning knobs of the plain forward: workgroups per CU it is compiled for, pixels whose gathers
+#define SCSFM_FWD_BLOCKS 4  // are in flight together
+#endif
+#ifndef SCSFM_FWD_GROUP
+#define SCSFM_FWD_GROUP 2
+#endif
 template <typename T, bool kSsim, bool kScaled>
-__global__ __launch_bounds__(kThreads) void pair_fwd_kernel(PairBatch<T> pb, int B, int H, int W, unsigned flags) {
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_FWD_BLOCKS : 1) void pair_fwd_kernel(PairBatch<T> pb, int B, int H, int W, unsigned flags) {
   const BlockId blk = xcd_block_id();
   const int pair = blk.z / B, b = blk.z - pair * B;
   const PairArgs<T>& pa = pb.p[pair];
@@ -145,6 +167,7 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(PairBatch<T> pb, int
   const unsigned plane = unsigned(H) * unsigned(W);
   tgt_img += (size_t)b * 3 * plane;
   ref_img += (size_t)b * 3 * plane;
+  const Planes3<T> tgtP = planes3(tgt_img, plane), refP = planes3(ref_img, plane);
   const DepthMap<T, kScaled> tgt_depth = depth_map<kScaled>(pa.tgt_depth, b, H, W, pa.ds);
   const DepthMap<T, kScaled> ref_depth = depth_map<kScaled>(pa.ref_depth, b, H, W, pa.ds);
 
@@ -154,40 +177,53 @@ __global__ __launch_bounds__(kThreads) void pair_fwd_kernel(PairBatch<T> pb, int
   T in_d[STRIP], in_t[STRIP][3], in_r[STRIP][3], rin_d = T(0), rin_t[3] = {T(0), T(0), T(0)}, rin_r[3];
 #pragma unroll
   for (int k = 0; k < STRIP; ++k)
-    load_pixel(u, reflect_index(ty0 + strip * STRIP + k, H), W, plane, tgt_img, ref_img, tgt_depth, with_auto, in_d[k],
-               in_t[k], in_r[k]);
+    load_pixel(u, reflect_index(ty0 + strip * STRIP + k, H), W, tgtP, refP, tgt_depth, with_auto, in_d[k], in_t[k], in_r[k]);
   const bool has_ring = kSsim && threadIdx.x < 2 * kHaloW + 2 * TH;
   int ru = 0, rv = 0, rhy = 0, rhx = 0;
   if (has_ring) {
     ring_pos<TH>(threadIdx.x, rhy, rhx);
     ru = reflect_index(tx0 + rhx - 1, W); rv = reflect_index(ty0 + rhy - 1, H);
-    load_pixel(ru, rv, W, plane, tgt_img, ref_img, tgt_depth, false, rin_d, rin_t, rin_r);
+    load_pixel(ru, rv, W, tgtP, refP, tgt_depth, false, rin_d, rin_t, rin_r);
   }
   // ---- phase 1a: the pixels this thread owns -------------------------------------------------
+  // (two pixels' gathers in flight together, as in the speculative forward)
+  constexpr int G = STRIP % SCSFM_FWD_GROUP == 0 ? SCSFM_FWD_GROUP : 1;
 #pragma unroll
-  for (int k = 0; k < STRIP; ++k) {
-    const int ly = strip * STRIP + k, gy = ty0 + ly;
-    const bool inimg = gx < W && gy < H;
-    const int v = reflect_index(gy, H);
-    V2 xy[3];
-    const Sample<T> s = warp_colours(bc, u, v, in_d[k], in_t[k], H, W, flags, ref_img, xy);
-    if (kSsim) {
+  for (int k0 = 0; k0 < STRIP; k0 += G) {
+    Sample<T> sm[G];
+    TapRows<T> tc[G][3], td[G];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) sXY[c][lrow + k + 1][col + 1] = xy[c];
+    for (int j = 0; j < G; ++j) {
+      sm[j] = project_pixel(bc, u, reflect_index(ty0 + strip * STRIP + k0 + j, H), in_d[k0 + j], H, W, flags);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tc[j][c] = load_tap_rows(refP, c, sm[j]);
+      td[j] = ref_depth.taps(sm[j]);
     }
-    l1sum[k] = clamp01(t_abs(xy[0][0] - xy[0][1])) + clamp01(t_abs(xy[1][0] - xy[1][1])) +
-               clamp01(t_abs(xy[2][0] - xy[2][1]));  // loss_functions.py:99, summed over colours
-    const T Dp = bilerp_rows(ref_depth.taps(s), s);
-    dd[k] = clamp01(t_abs(s.Z - Dp) * t_rcp(s.Z + Dp));  // loss_functions.py:101
-    m[k] = inimg ? pixel_mask(s, with_auto, xy, in_r[k]) : T(0);
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int k = k0 + j, ly = strip * STRIP + k, gy = ty0 + ly;
+      const bool inimg = gx < W && gy < H;
+      const Sample<T>& s = sm[j];
+      V2 xy[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xy[c] = make2(in_t[k][c], bilerp_rows(tc[j][c], s));
+      if (kSsim) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sXY[c][lrow + k + 1][col + 1] = xy[c];
+      }
+      l1sum[k] = clamp01(t_abs(xy[0][0] - xy[0][1])) + clamp01(t_abs(xy[1][0] - xy[1][1])) +
+                 clamp01(t_abs(xy[2][0] - xy[2][1]));  // loss_functions.py:99, summed over colours
+      const T Dp = bilerp_rows(td[j], s);
+      dd[k] = clamp01(t_abs(s.Z - Dp) * t_rcp(s.Z + Dp));  // loss_functions.py:101
+      m[k] = inimg ? pixel_mask(s, with_auto, xy, in_r[k]) : T(0);
+    }
   }
   // ---- phase 1b: the 1-pixel ring (SSIM windows of the tile's border pixels) ------------------
   if (kSsim) {
     if (has_ring) {
-      V2 xy[3];
-      warp_colours(bc, ru, rv, rin_d, rin_t, H, W, flags, ref_img, xy);
+      const Sample<T> rs = project_pixel(bc, ru, rv, rin_d, H, W, flags);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) sXY[c][rhy][rhx] = xy[c];
+      for (int c = 0; c < 3; ++c) sXY[c][rhy][rhx] = make2(rin_t[c], bilerp_rows(load_tap_rows(refP, c, rs), rs));
     }
     __syncthreads();
   }
