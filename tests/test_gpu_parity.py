@@ -826,3 +826,38 @@ def test_baseline_size_fixture_recorded_from_the_reference(LF, dev):
         for nm, t in ((f"g_pose{i}", ps[i]), (f"g_pose_inv{i}", pi[i])):
             want = z[nm].astype(np.float64)
             assert float(np.abs(t.grad.cpu().numpy() - want).max()) <= POSE_RTOL * float(np.abs(want).max()), nm
+
+
+def test_inputs_at_odd_element_offsets_give_the_same_results(dev, LF):
+    """Every tensor of a step sliced out of a larger allocation at an offset of 1 or 3 elements (4-byte aligned, no
+    more): the buffer resources of the image planes, the 16-byte paths of the combining / clearing / smooth kernels and
+    their scalar fall-backs must not care where a tensor starts."""
+    from scsfm_hip import synth
+    B, H, W = 4, 72, 100
+    d = synth.make_batch(B, H, W, n_ref=2, seed=41, depth="smooth")
+
+    def shifted(t, k):
+        buf = torch.empty(t.numel() + 8, dtype=t.dtype, device=dev)
+        v = buf[k:k + t.numel()].view(t.shape)
+        v.copy_(t)
+        assert v.is_contiguous() and v.data_ptr() % 16 == (buf.data_ptr() + 4 * k) % 16
+        return v
+
+    def run(k):
+        g = lambda t, r=False: shifted(t.float(), k).requires_grad_(r) if k else t.float().to(dev).requires_grad_(r)
+        ti, K = g(d["tgt_img"]), g(d["intrinsics"])
+        ris = [g(r) for r in d["ref_imgs"]]
+        td, rd = [g(d["tgt_depth"][0], True)], [[g(r[0], True)] for r in d["ref_depths"]]
+        pp, pi = [g(p, True) for p in d["poses"]], [g(p, True) for p in d["poses_inv"]]
+        photo, geom = LF.compute_photo_and_geometry_loss(ti, ris, K, td, rd, pp, pi, 1, 1, 1, 1, "zeros")
+        smooth = LF.compute_smooth_loss(td, ti, rd, ris)
+        (photo + 0.1 * smooth + 0.5 * geom).backward()
+        return [photo.detach(), geom.detach(), smooth.detach(), td[0].grad, rd[0][0].grad, rd[1][0].grad, pp[0].grad, pi[1].grad]
+
+    ref = run(0)
+    for k in (1, 3):
+        got = run(k)
+        for a, b in zip(got[:3], ref[:3]):
+            assert torch.equal(a, b)
+        for a, b in zip(got[3:], ref[3:]):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
