@@ -1,0 +1,74 @@
+"""Properties of the COMPILED product kernel that its speed rests on and that no numerical test sees: the dominant
+kernel must fit four workgroups per CU (<= 128 VGPRs, <= 40 KB of LDS), spill nothing, and address the image planes
+through buffer resources held in SCALAR registers -- under register pressure the allocator is free to move a
+descriptor into vector registers, and every load through it then becomes a waterfall loop (v_readfirstlane /
+s_cbranch_execnz around each buffer_load: +30 % instructions, seen while experimenting in round 3).  hipcc
+cross-compiles gfx950 without a GPU; the listing is parsed here.  Skipped where there is no hipcc."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "sc-sfmlearner-release_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+PRODUCT = "_ZN5scsfm20pair_fwd_spec_kernelIfLb1ELj7ELb0ELb0"  # <float, ssim, training flags, full resolution, no forward staging>
+PLAIN = "_ZN5scsfm15pair_fwd_kernelIfLb1ELb0"
+
+
+@pytest.fixture(scope="module")
+def listing(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc on this machine")
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "sc-sfmlearner-release_amd"))
+    from scsfm_hip import build
+    out = tmp_path_factory.mktemp("isa") / "pair.s"
+    flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.run([HIPCC, *flags, "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-o", str(out),
+                    os.path.join(CSRC, "scsfm_pair.hip")], check=True, capture_output=True)
+    return open(out).read().split("\n")
+
+
+def _kernel(lines, prefix):
+    start = next(i for i, l in enumerate(lines) if l.startswith(prefix) and l.rstrip().split(":")[0].startswith(prefix))
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    meta = {}
+    for l in lines[end:end + 400]:
+        m = re.match(r";\s*(NumVgprs|ScratchSize|LDSByteSize|Occupancy|NumSgprs):\s*(\d+)", l)
+        if m and m.group(1) not in meta:
+            meta[m.group(1)] = int(m.group(2))
+        if l.startswith("; Occupancy"):
+            break
+    return lines[start:end], meta
+
+
+def _waterfalls(body):
+    """buffer loads that sit in a loop which re-reads its descriptor lane by lane"""
+    n = 0
+    for i, l in enumerate(body):
+        if "buffer_load" in l and any("v_readfirstlane_b32" in x for x in body[max(0, i - 12):i]) and \
+                any("s_cbranch_execnz" in x for x in body[i:i + 4]):
+            n += 1
+    return n
+
+
+def test_the_dominant_kernel_fits_four_workgroups_per_cu_and_spills_nothing(listing):
+    body, meta = _kernel(listing, PRODUCT)
+    assert meta["NumVgprs"] <= 128 and meta["ScratchSize"] == 0, meta
+    assert meta["LDSByteSize"] <= 160 * 1024 // 4, meta
+    assert meta["Occupancy"] >= 4, meta
+    loads = sum("buffer_load" in l for l in body)
+    assert loads >= 90, "the image planes are read through buffer resources"
+    assert _waterfalls(body) == 0
+    assert sum(l.strip().startswith("v_lshl_add_u64") for l in body) <= 12, "64-bit vector address arithmetic is back"
+    valu = sum(1 for l in body if l.startswith("\tv_"))
+    assert valu <= 2700, f"{valu} vector instructions per thread (round 3: 2599)"
+
+
+def test_the_plain_forward_spills_nothing(listing):
+    body, meta = _kernel(listing, PLAIN)
+    assert meta["ScratchSize"] == 0 and meta["NumVgprs"] <= 128, meta
+    assert _waterfalls(body) == 0
