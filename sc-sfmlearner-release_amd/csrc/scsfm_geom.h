@@ -579,18 +579,40 @@ __device__ __forceinline__ float win_value(int c) { return float(c) * kFixInv; }
 __device__ __forceinline__ double win_value(double c) { return c; }
 __device__ __forceinline__ float win_value(float c) { return c; }
 
+// The WIDE window of a tile whose footprint is much taller than the window proper (incoherent depth: a direct global
+// atomic per lane is the most expensive thing the scatter does -- moving the 17 % of an iid tile's taps that the window
+// catches to direct atomics was measured at +160 us per launch).  Such a tile's tail finds next to none of its texels in
+// the staged window either, so it does without staging and spends the three staging regions (kWideRows rows of WW cells
+// each, one behind the parked gradients of every colour tile) on more window: row WH + 12 r + q (q < 12) lives at
+// ext + r * ext_stride + q * WW, i.e. at its place in a contiguous window plus r * step + off cells.
+struct WideWin {
+  int rows;       // WH, or WH + 3 * kWideRows for a wide tile (uniform over the workgroup)
+  int off, step;  // cells: (ext - window) - WH * WW, and ext_stride - kWideRows * WW
+};
+constexpr int kWideRows = 12;
+template <int WH>
+__device__ __forceinline__ int wide_adjust(const WideWin& ww, int ly) {  // only called when ww.rows > WH
+  const int e = ly - WH;
+  const int r = (e * 43) >> 9;  // e / 12 for 0 <= e < 36
+  return e >= 0 ? ww.off + r * ww.step : 0;
+}
+
 template <typename T, typename Cell, int WW, int WH>
 __device__ __forceinline__ void scatter_taps_window(Cell (*win)[WW], int wx0, int wy0,
-                                                    T* __restrict__ gplane, const Sample<T>& s, T g) {
+                                                    T* __restrict__ gplane, const Sample<T>& s, T g,
+                                                    const WideWin& ww = WideWin{WH, 0, 0}) {
   if (g == T(0)) return;
   const int lx = s.xa - wx0, ly = s.ya - wy0;
-  if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < WH - 1 && win_fits(&win[0][0], g)) {
+  if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < ww.rows - 1 && win_fits(&win[0][0], g)) {
     // unpredicated: a cell of the block that is not a tap has weight 0, and adding 0 leaves it at the 0 the flush skips
     const T gu = win_unit(&win[0][0], g);
-    win_add(&win[ly][lx], gu * s.wp[0]);
-    win_add(&win[ly][lx + 1], gu * s.wp[1]);
-    win_add(&win[ly + 1][lx], gu * s.wp[2]);
-    win_add(&win[ly + 1][lx + 1], gu * s.wp[3]);
+    Cell* rn = &win[0][0] + ly * WW + lx;
+    Cell* rs = rn + WW;
+    if (ww.rows > WH) { rn += wide_adjust<WH>(ww, ly); rs += wide_adjust<WH>(ww, ly + 1); }  // (uniform branch)
+    win_add(rn, gu * s.wp[0]);
+    win_add(rn + 1, gu * s.wp[1]);
+    win_add(rs, gu * s.wp[2]);
+    win_add(rs + 1, gu * s.wp[3]);
   } else {
     scatter_taps(gplane, s, g);
   }
@@ -612,16 +634,17 @@ __device__ __forceinline__ void flush_scatter_window(const Cell (*win)[WW], int 
 // half as many atomic instructions are issued, each with (nearly) all of its lanes active.
 template <typename T, typename Cell, int WW, int WH, int NT = kThreads>
 __device__ __forceinline__ void flush_scatter_region(const Cell (*win)[WW], int wx0, int wy0, int cx0,
-                                                     int cy0, int cx1, int cy1, T* __restrict__ gplane, int W) {
+                                                     int cy0, int cx1, int cy1, T* __restrict__ gplane, int W,
+                                                     const WideWin& ww = WideWin{WH, 0, 0}) {
   cx0 = cx0 < 0 ? 0 : cx0; cy0 = cy0 < 0 ? 0 : cy0;
-  cx1 = cx1 > WW - 1 ? WW - 1 : cx1; cy1 = cy1 > WH - 1 ? WH - 1 : cy1;
+  cx1 = cx1 > WW - 1 ? WW - 1 : cx1; cy1 = cy1 > ww.rows - 1 ? ww.rows - 1 : cy1;
   const int w = cx1 - cx0 + 1, h = cy1 - cy0 + 1;
   if (w <= 0 || h <= 0) return;
   const float iw = 1.0f / float(w);
   for (int i = threadIdx.x; i < w * h; i += NT) {
     const int ry = int((float(i) + 0.5f) * iw);  // i / w, exact for the few thousand cells of a window
     const int ly = cy0 + ry, lx = cx0 + (i - ry * w);
-    const Cell v = win[ly][lx];
+    const Cell v = (&win[0][0])[ly * WW + lx + (ww.rows > WH ? wide_adjust<WH>(ww, ly) : 0)];
     if (v != Cell(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), T(win_value(v)));
   }
 }
@@ -739,7 +762,7 @@ __device__ __forceinline__ void fwd_taps(const Sample<T>& s, bool staged, int fx
 template <typename T, typename Cell, int WW, int WH>
 __device__ __forceinline__ T geom_consume(const BatchConsts<T>& bc, const GeomTaps<T>& f, int px, int py, T d, const T (&gI)[3], T g_dd,
                                           int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
-                                          T* __restrict__ scatter_plane, T* acc) {
+                                          T* __restrict__ scatter_plane, T* acc, const WideWin& ww = WideWin{WH, 0, 0}) {
   const Sample<T>& s = f.s;
   const TapRows<T>(&tc)[3] = f.tc;
   const TapRows<T>& td = f.td;
@@ -762,7 +785,7 @@ __device__ __forceinline__ T geom_consume(const BatchConsts<T>& bc, const GeomTa
   t.s.b = gI[0] * tc[0].s.b + gI[1] * tc[1].s.b + gI[2] * tc[2].s.b + gDp * td.s.b;
   T gix, giy;
   tap_rows_grad(t, s, gix, giy);
-  if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, Cell, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp);
+  if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, Cell, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp, ww);
   return pixel_geometry_bwd(bc, s, px, py, d, gix, giy, gZ, H, W, acc);
 }
 template <typename T, typename Cell, int WW, int WH, typename Map>

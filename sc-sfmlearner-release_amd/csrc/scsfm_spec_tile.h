@@ -375,6 +375,12 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
   // kSpec: the window goes where the block's pixels land: around the bounding box of their north-west taps (known
   // since the warp), centred on it when it is larger than the window (the rest falls back to global atomics)
   int wx0 = 0, wy0 = 0, cx0 = 0, cy0 = 0, cx1 = 0, cy1 = 0;  // window origin; cells of the window the taps can reach
+#ifndef SCSFM_WIDE_WINDOW  // tuning knob: 0 = no wide window for incoherent footprints
+#define SCSFM_WIDE_WINDOW 1
+#endif
+  // (the wide window needs the lean layout -- its extension rows are the staging regions -- and 32-bit cells)
+  constexpr bool kWideOk = SCSFM_WIDE_WINDOW && SCSFM_LEAN_LDS && SCSFM_STAGE_TAPS && kSpec && kSsim && sizeof(T) == 4 && TH == kTileH;
+  int wrows = WH;
   auto scatter_box = [&]() {
     int x0 = sBox[0][0], x1 = sBox[0][1], y0 = sBox[0][2], y1 = sBox[0][3];
 #pragma unroll
@@ -384,8 +390,10 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     }
     if (x0 > x1) { x0 = x1 = 0; y0 = y1 = 0; }  // nothing scatters
     const int ex = x1 - x0 + 2, ey = y1 - y0 + 2;  // cells touched (each pixel reaches one past its tap)
+    // a footprint more than twice as tall as the window: the wide window (scsfm_geom.h: WideWin), no staged taps
+    wrows = (kWideOk && ey > 2 * WH) ? WH + 3 * kWideRows : WH;
     wx0 = ex <= WW ? x0 - (WW - ex) / 2 : (x0 + x1 + 1) / 2 - WW / 2;
-    wy0 = ey <= WH ? y0 - (WH - ey) / 2 : (y0 + y1 + 1) / 2 - WH / 2;
+    wy0 = ey <= wrows ? y0 - (wrows - ey) / 2 : (y0 + y1 + 1) / 2 - wrows / 2;
     cx0 = x0 - wx0; cx1 = x1 + 1 - wx0; cy0 = y0 - wy0; cy1 = y1 + 1 - wy0;
   };
   // kStage (fp32 + SSIM): the texels the geometry tail samples -- the reference view's colours and depth around
@@ -528,7 +536,10 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     T* __restrict__ g_dense = pa.gbuf + kPlaneDense * gplane + (size_t)b * plane;
     T* __restrict__ g_scatter = pa.gbuf + kPlaneScatter * gplane + (size_t)b * plane;
     if constexpr (!kSsim) scatter_box();  // (with SSIM: done after the warp phase's barrier)
-    if constexpr (kStage && !SCSFM_STAGE_EARLY) SCSFM_ISSUE_STAGE_LOADS();
+    const bool wide = kWideOk && __builtin_amdgcn_readfirstlane(wrows) > WH;  // (uniform: every thread read the same boxes)
+    if constexpr (kStage && !SCSFM_STAGE_EARLY) {
+      if (!wide) SCSFM_ISSUE_STAGE_LOADS();
+    }
     T d_own[STRIP];  // depth of the owned pixels: kept since phase 0, or (kLean: 4 registers less across the SSIM phases) re-read
 #pragma unroll
     for (int k = 0; k < STRIP; ++k) {
@@ -542,7 +553,21 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     if constexpr (kLean) {  // the window (in sG, dead since the barrier of the block sum above)
       for (int i = threadIdx.x; i < WW * WH; i += kThreads) (&win[0][0])[i] = Cell(0);
     }
+    WideWin ww{WH, 0, 0};
     if constexpr (kStage) {
+      if (wide) {
+        // the staging regions become window rows: cleared, and no block of the tail lies "inside" a staged window
+        static_assert(!kWideOk || (kStageW * kStageRows >= kWideRows * WW && sizeof(Cell) == sizeof(T)), "wide window rows");
+        for (int i = threadIdx.x; i < 3 * kWideRows * WW; i += kThreads) {
+          const int r = i / (kWideRows * WW);
+          reinterpret_cast<Cell*>(sp_colour)[r * kTileFloats + (i - r * kWideRows * WW)] = Cell(0);
+        }
+        staged.x0 = 1 << 28; staged.y0 = 1 << 28;
+        staged.colour = sp_colour; staged.depth = sp_depth; staged.stride = kTileFloats;
+        ww.rows = WH + 3 * kWideRows;
+        ww.off = int(reinterpret_cast<Cell*>(sp_colour) - &win[0][0]) - WH * WW;
+        ww.step = kTileFloats - kWideRows * WW;
+      } else {
       // ... and go to LDS: the tiles and sG are dead by now
 #pragma unroll
       for (int i = 0; i <= NR; ++i) {
@@ -553,6 +578,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
           for (int c = 0; c < 3; ++c) sp_colour[c * kTileFloats + r * kStageW + cc] = stage_v[c][i];
           if (!kLean) sp_depth[r * kStageW + cc] = stage_v[3][i];
         }
+      }
       }
       __syncthreads();
     }
@@ -572,7 +598,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
       }
       if constexpr (kStage) {
         const GeomTaps<T> f = geom_fetch<kStageRows, !kLean>(bc, px, py, d_own[k], refP, ref_depth, H, W, flags, staged);
-        gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, d_own[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc);
+        gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, d_own[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc, ww);
       } else {
         gd[k] = geom_pixel<T, Cell, WW, WH>(bc, px, py, d_own[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
                                       wy0, g_scatter, acc);
@@ -593,7 +619,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
         st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gd[k]);
     }
     if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5)))
-      flush_scatter_region<T, Cell, WW, WH>(win, wx0, wy0, cx0, cy0, cx1, cy1, g_scatter, W);
+      flush_scatter_region<T, Cell, WW, WH>(win, wx0, wy0, cx0, cy0, cx1, cy1, g_scatter, W, ww);
     STAMP(8);
   }
 }

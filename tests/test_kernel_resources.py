@@ -63,9 +63,13 @@ def test_the_dominant_kernel_fits_four_workgroups_per_cu_and_spills_nothing(list
     loads = sum("buffer_load" in l for l in body)
     assert loads >= 90, "the image planes are read through buffer resources"
     assert _waterfalls(body) == 0
-    assert sum(l.strip().startswith("v_lshl_add_u64") for l in body) <= 12, "64-bit vector address arithmetic is back"
+    # (the global atomics of the scatter form their 64-bit addresses in vector registers -- about 18; the image loads
+    # used to add 75 to that)
+    assert sum(l.strip().startswith("v_lshl_add_u64") for l in body) <= 30, "64-bit vector address arithmetic is back"
     valu = sum(1 for l in body if l.startswith("\tv_"))
-    assert valu <= 2700, f"{valu} vector instructions per thread (round 3: 2599)"
+    # (static count: 2599 on the path of a tile with a coherent footprint + the uniformly skipped code of the wide
+    # scatter window)
+    assert valu <= 2850, f"{valu} vector instructions per thread (round 3: 2773)"
 
 
 def test_the_plain_forward_spills_nothing(listing):

@@ -98,3 +98,28 @@ def test_staged_window_misses_fall_back_to_gathers(lib, monkeypatch):
     for i in range(2):
         assert torch.equal(tile[2][2][i], staged[2][2][i]) and torch.equal(tile[2][3][i], staged[2][3][i])
         assert _rel(staged[2][1][i][0], tile[2][1][i][0]) < 1e-5
+
+
+def test_wide_scatter_window_on_incoherent_depth(lib, monkeypatch):
+    """Footprints more than twice as tall as the scatter window (iid depth on an image tall enough for taps +-48 rows
+    away): the tile kernel widens the window with its three staging regions (csrc/scsfm_geom.h: WideWin) and does
+    without staged taps.  Against the fp64 oracle with the allowance of the iid cases, and against the backward's own
+    two passes (plain forward, floating-point window of the normal size), which share no scatter code with it."""
+    monkeypatch.delenv("SCSFM_SPEC_KERNEL", raising=False)
+    d = synth.make_batch(3, 160, 100, n_ref=2, seed=23, depth="iid", image="iid")
+    po, go, td, rd, pp, pi = _oracle(d, "zeros")
+    assert float(po) > 0 and float(go) > 0
+    photo, geom, g = _run(lib, d, "zeros")
+    assert abs(float(photo) - float(po)) <= 1e-5 and abs(float(geom) - float(go)) <= 1e-5
+    ti, K, ris = d["tgt_img"], d["intrinsics"], d["ref_imgs"]
+    tds, rds = [d["tgt_depth"][0]], [[r[0]] for r in d["ref_depths"]]
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    _, _, _, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, d["poses"], d["poses_inv"])  # no speculation
+    g2 = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, d["poses"], d["poses_inv"], ws, torch.tensor([1.0]),
+                                 torch.tensor([0.5]))
+    assert _rel(g[0][0], g2[0][0]) < 2e-4
+    for i in range(2):
+        assert _rel(g[1][i][0], g2[1][i][0]) < 2e-4
+        assert _rel(g[2][i], g2[2][i]) < 1e-3
+        ref = rd[i][0].grad.numpy()
+        assert_close_frac(g[1][i][0].numpy(), ref, atol=2e-3 * abs(ref).max(), rtol=1e-3, max_bad_frac=3e-2, what=f"ref depth {i}")
