@@ -90,22 +90,29 @@ def hot_path_step_single_node(LF, x, flags):
     return loss, photo, smooth, geom
 
 
-def pmc_traffic(args, n_pairs):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_latest.json:
-    FETCH_SIZE + WRITE_SIZE in KiB per dispatch, collected in separate `rocprofv3 --pmc` runs of this very
-    command -- tools/gpu_round.sh).  Only quoted for the workload the counters were collected on."""
+def pmc_traffic(args, n_pairs, lib_source_id):
+    """-> (HBM bytes per launch of the dominant kernel | None, why).  The bytes are QUOTED from the committed PMC passes
+    (profiles/pmc_latest.json: FETCH_SIZE + WRITE_SIZE in KiB per dispatch, collected in separate `rocprofv3 --pmc` runs
+    of this very command -- tools/gpu_round.sh), and only for the workload AND the library they were collected on: the
+    file records the source id of the library that ran (`_library_source_id`), and a loaded library with another id --
+    a later kernel change -- gets None instead of the old counters."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if not os.path.exists(path) or (args.batch, args.height, args.width, args.n_ref, args.depth) != (12, 256, 832, 2, "smooth"):
-        return None
+    if not os.path.exists(path):
+        return None, "no profiles/pmc_latest.json"
+    if (args.batch, args.height, args.width, args.n_ref, args.depth) != (12, 256, 832, 2, "smooth"):
+        return None, "counters were collected on configs[1] only"
     try:
         d = json.load(open(path))
+        have = d.get("_library_source_id")
+        if have != lib_source_id:
+            return None, f"counters are those of library {have}, the loaded one is {lib_source_id}: re-run tools/gpu_round.sh"
         gz = n_pairs * args.batch
         # the training-flags instantiation of the speculative forward (the template list grew over the rounds)
         keys = [n for n in d if n.startswith("scsfm::pair_fwd_spec_kernel<float, true, 7u") and n.endswith(f"|gz{gz}")]
         k = d[keys[0]]
-        return int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
-    except (KeyError, ValueError, IndexError):
-        return None
+        return int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024), "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_round.sh on this library)"
+    except (KeyError, ValueError, IndexError, TypeError):
+        return None, "profiles/pmc_latest.json has no entry for the dominant kernel"
 
 
 def _event_time(fn, iters):
@@ -337,13 +344,11 @@ def main():
     dist_on = world > 1 or args.force_dist != "none"
     if dist_on:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from scsfm_hip import dist as hip_dist
         os.environ.setdefault("MASTER_PORT", "29533")
         backend = "gloo" if shared_gpu else ("nccl" if world > 1 else args.force_dist)
-        if backend == "gloo":
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        # (the same call train.py makes: nccl bound to this rank's device, gloo for ranks sharing a GPU)
+        hip_dist.init_process_group(backend, rank, world, device, force=True)
 
     import loss_functions as LF
     from scsfm_hip import _lib
@@ -476,12 +481,14 @@ def main():
     # time_kernels (inputs still in the Infinity Cache from the previous launch) is reported beside it
     launch_s = in_step_us[0] * 1e-6 if in_step_us[2] > 0 else kt["spec_kernel_only"]
     achieved = spec_bytes / launch_s / 1e9
+    traffic, traffic_why = pmc_traffic(args, n_pairs, ident["source_id_in_binary"])
     roofline = {"bound": "hbm", "kernel": f"{DOMINANT_KERNEL} ({n_pairs} pair-directions per launch)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, n_pairs),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 # (HBM bytes per launch = FETCH_SIZE + WRITE_SIZE of separate `rocprofv3 --pmc` passes of this command,
-                # QUOTED from the committed profiles/pmc_latest.json -- counters cannot be read inside a timed run)
-                "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_round.sh)",
+                # QUOTED from the committed profiles/pmc_latest.json -- counters cannot be read inside a timed run --
+                # and only when that file was recorded on the library loaded here)
+                "traffic_source": traffic_why,
                 # of the 48 B/px booked on this kernel 8 B/px (the read-modify-write of the gradient maps) are paid by
                 # pairs_combine_kernel: the kernel's own algorithmic bytes are 40 B/px
                 "kernel_own_algorithmic_bytes_per_launch": int(spec_bytes / 48 * 40),

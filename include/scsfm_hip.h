@@ -379,6 +379,11 @@ int scsfm_step_weights_f64(const double* g_loss, double w_photo, double w_smooth
  * (prepared on the host as Pillow's precompute_coeffs + normalize_coeffs_8bpc do, for the cropped window);
  * lut [256] = the float a byte maps to; out: fp32 [frames_per_sample, n_samples, 3, H, W] (store): frame-major,
  * so that out[t] is the contiguous batch of the t-th frame of every sample.
+ * PRECONDITION on the tables: those of a zoom-in resize (output size >= the cropped source window, as RandomScaleCrop
+ * produces: custom_transforms.py:62-84) with monotone first indices and at most 5 taps -- a 64 x 16 tile of outputs then
+ * reads at most 69 x 21 source pixels, which is what the kernel stages in LDS.  Tables outside that class are not
+ * rejected (they live on the device); the kernel clamps every index they imply into its staging arrays, so such a call
+ * returns meaningless pixels but never touches memory it does not own.
  * --------------------------------------------------------------------------------------------- */
 int scsfm_augment_u8_f32(int n_frames, int frames_per_sample, int H, int W, const unsigned char* frames,
                          const int* params, const int* htab, const int* vtab, const float* lut, float* out,

@@ -58,7 +58,12 @@ __global__ __launch_bounds__(kThreads) void augment_kernel(int T, int H, int W, 
   const int v0 = vt[8 * y0], v1 = vt[8 * yl] + vt[8 * yl + 1];
   const int h0 = ht[8 * x0], h1 = ht[8 * xl] + ht[8 * xl + 1];
   // in frame coordinates a flipped tile reads columns W - h1 .. W - 1 - h0
-  const int c0 = flip ? W - h1 : h0, nrows = v1 - v0;  // (columns: h1 - h0 <= 64 + 5)
+  // PRECONDITION (include/scsfm_hip.h): tables of a zoom-in resize with at most 5 taps, so that a tile's window spans
+  // at most kAugSrcRows x kAugSrcCols source pixels.  Tables that break it (the C entry point takes any) must not
+  // reach beyond the two LDS arrays: the row count, every window column and every tap row are clamped -- such a call
+  // returns meaningless pixels, not a fault.
+  const int c0 = flip ? W - h1 : h0;  // (columns: h1 - h0 <= 64 + 5)
+  const int nrows = v1 - v0 < 0 ? 0 : (v1 - v0 > kAugSrcRows ? kAugSrcRows : v1 - v0);
   const uint8_t* __restrict__ src = frames + (size_t)f * H * W * 3;
   // ---- 1. window -> LDS (dwords from the 4-byte aligned address at or before the window's first byte of each row)
   const uint8_t* const buf_end = frames + (size_t)gridDim.z * H * W * 3;
@@ -90,7 +95,8 @@ __global__ __launch_bounds__(kThreads) void augment_kernel(int T, int H, int W, 
       for (int i = 0; i < 5; ++i) {
         if (i < hcnt) {
           const int col = hmin + i;                                        // column of the (flipped) frame
-          const int wc = flip ? (W - 1 - col) - c0 : col - c0;             // ... inside the window
+          int wc = flip ? (W - 1 - col) - c0 : col - c0;                   // ... inside the window
+          wc = wc < 0 ? 0 : (wc > kAugSrcCols - 1 ? kAugSrcCols - 1 : wc);  // (no-op under the precondition)
           const uint8_t* __restrict__ px = row + 3 * wc;
           h[0] += int(px[0]) * k[i]; h[1] += int(px[1]) * k[i]; h[2] += int(px[2]) * k[i];
         }
@@ -109,8 +115,10 @@ __global__ __launch_bounds__(kThreads) void augment_kernel(int T, int H, int W, 
     const int* __restrict__ vb = vt + 8 * y;
     const int vmin = vb[0], vcnt = vb[1];
     int acc[3] = {1 << (kAugPrec - 1), 1 << (kAugPrec - 1), 1 << (kAugPrec - 1)};
-    for (int i = 0; i < vcnt; ++i) {
-      const uint32_t p = sH[vmin - v0 + i][lane];
+    for (int i = 0; i < (vcnt < 5 ? vcnt : 5); ++i) {
+      int r = vmin - v0 + i;
+      r = r < 0 ? 0 : (r > kAugSrcRows - 1 ? kAugSrcRows - 1 : r);  // (no-op under the precondition)
+      const uint32_t p = sH[r][lane];
       const int kk = vb[2 + i];
       acc[0] += int(p & 255u) * kk; acc[1] += int((p >> 8) & 255u) * kk; acc[2] += int(p >> 16) * kk;
     }

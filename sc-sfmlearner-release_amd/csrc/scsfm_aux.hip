@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void masked_mean_bwd_mask_kernel(long nm,
 template <typename T>
 static int ssim_fwd(int N, int H, int W, const T* x, const T* y, T* out, void* stream) {
   clear_status();
-  if (N <= 0 || H < 2 || W < 2 || !x || !y || !out) return SCSFM_ERR_ARG;
+  if (N <= 0 || H < 2 || W < 2 || !dims_ok<T>(N, H, W) || !x || !y || !out) return SCSFM_ERR_ARG;
   hipLaunchKernelGGL((ssim_fwd_kernel<T>), dim3(ceil_div(W, kTileW), ceil_div(H, Tile<T>::kH), N), dim3(kThreads), 0,
                      (hipStream_t)stream, H, W, x, y, out);
   return launch_status();
@@ -174,7 +174,7 @@ static int ssim_fwd(int N, int H, int W, const T* x, const T* y, T* out, void* s
 template <typename T>
 static int ssim_bwd(int N, int H, int W, const T* x, const T* y, const T* g_out, T* g_x, T* g_y, void* stream) {
   clear_status();
-  if (N <= 0 || H < 2 || W < 2 || !x || !y || !g_out || (!g_x && !g_y)) return SCSFM_ERR_ARG;
+  if (N <= 0 || H < 2 || W < 2 || !dims_ok<T>(N, H, W) || !x || !y || !g_out || (!g_x && !g_y)) return SCSFM_ERR_ARG;
   hipLaunchKernelGGL((ssim_bwd_kernel<T>), dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), N),
                      dim3(kThreads), 0, (hipStream_t)stream, H, W, x, y, g_out, g_x, g_y);
   return launch_status();

@@ -64,6 +64,14 @@ inline int launch_status() { return (int)hipGetLastError(); }
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// What every entry point that takes (B, H, W) checks before it launches anything (SCSFM_ERR_ARG otherwise): the kernels
+// address the three colour planes of ONE image of the batch with 32-bit byte offsets from a wave-uniform base, and the
+// batched launches put (pair or frame, batch element) on the grid's z axis (<= 65535; up to kMaxPairs = 8 per launch).
+template <typename T>
+inline bool dims_ok(int B, int H, int W) {
+  return B > 0 && B <= 8191 && H >= 1 && W >= 1 && (unsigned long long)3 * (unsigned long long)H * (unsigned long long)W * sizeof(T) < (1ull << 32);
+}
+
 inline PairWs pair_ws_layout(int B, int H, int W) {
   PairWs l;
   l.nbx = ceil_div(W, kTileW);
@@ -173,10 +181,31 @@ __device__ __forceinline__ void block_sum_store(T (&v)[N], double* scratch, doub
 // i.e. whole images per XCD.
 struct BlockId { int x, y, z; };
 // p = linear id of a workgroup that the dispatcher placed on XCD p % 8 -> the logical tile it should process
+// Chunked (round 4): the logical order is cut into chunks of C tiles and chunk j goes to XCD j % 8, so that an XCD works on
+// every eighth chunk instead of on one contiguous eighth of the launch: with C = 266 -- one 256 x 832 image -- the images of
+// a pair-direction, whose tiles cost alike, are spread over all XCDs and none of them is left working alone at the end
+// (-1.5 % on the speculative forward; the locality that matters, between neighbouring tiles of an image, is kept; other
+// image sizes get chunks of a few whole or fractional images, which is as good).  C is a compile-time constant on purpose:
+// derived from the grid (nx * ny) it costs a scalar division and two live scalars, and the speculative forward sits at
+// the limit of its 102 scalar registers -- the allocator then moves the images' buffer descriptors into vector
+// registers and every load through them becomes a waterfall loop (+35 % vector instructions, measured in round 4).
+// SCSFM_XCD_CHUNK (tuning knob): 0 = one contiguous eighth per XCD (rounds 1-3), n = n tiles per chunk.
+#ifndef SCSFM_XCD_CHUNK
+#define SCSFM_XCD_CHUNK 266
+#endif
 __device__ __forceinline__ BlockId xcd_tile_of(int p, int nx, int ny, int nz) {
   const int n = nx * ny * nz;
-  const int xcd = p & 7, slot = p >> 3, q = n >> 3, r = n & 7;
-  const int l = xcd * q + (xcd < r ? xcd : r) + slot;
+  const int xcd = p & 7, slot = p >> 3;
+  constexpr int C = SCSFM_XCD_CHUNK;
+  // tiles per XCD that whole chunks cover; the rest of the launch keeps the contiguous split
+  const int full = C > 0 ? ((n >> 3) / C) * C : 0;
+  int l;
+  if (C > 0 && slot < full) {
+    l = ((slot / C) * 8 + xcd) * C + slot % C;
+  } else {
+    const int m = n - 8 * full, q = m >> 3, r = m & 7;
+    l = 8 * full + xcd * q + (xcd < r ? xcd : r) + (slot - full);
+  }
   BlockId b;
   b.x = l % nx;
   const int t = l / nx;
@@ -218,7 +247,7 @@ __device__ __forceinline__ void t_sincos(float x, float* s, float* c) { *s = sin
 __device__ __forceinline__ void t_sincos(double x, double* s, double* c) { *s = sin(x); *c = cos(x); }
 // Load at a 32-bit byte offset from a wave-uniform base: compiles to the scalar-base addressing mode
 // (global_load ... v_off, s[base:base+1]) with no 64-bit vector address arithmetic.  Every plane this
-// library indexes that way is far below 4 GiB (checked on the host side).
+// library indexes that way is below 4 GiB: the entry points reject larger images (dims_ok below).
 // A read that must stay an LDS access: behind an if / else whose other side reads global memory the optimiser would
 // otherwise select between the two pointers and issue ONE flat load (through the texture path) for both.
 template <typename T>

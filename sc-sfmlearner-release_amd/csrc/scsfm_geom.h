@@ -632,6 +632,13 @@ __device__ __forceinline__ void flush_scatter_window(const Cell (*win)[WW], int 
 // The same flush restricted to the cells [cx0, cx1] x [cy0, cy1] of the window (inclusive, window coordinates;
 // clamped into it) that can be non-zero: the bounding box of the block's taps is usually half the window, so
 // half as many atomic instructions are issued, each with (nearly) all of its lanes active.
+#ifndef SCSFM_FLUSH_STEP  // tuning knob: 0 = the flush of rounds 1-3 (a division per cell)
+#define SCSFM_FLUSH_STEP 1
+#endif
+template <typename T>
+__device__ __forceinline__ void atomic_add_at(T* __restrict__ base, unsigned byte_off, T v) {
+  atomicAdd(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v);
+}
 template <typename T, typename Cell, int WW, int WH, int NT = kThreads>
 __device__ __forceinline__ void flush_scatter_region(const Cell (*win)[WW], int wx0, int wy0, int cx0,
                                                      int cy0, int cx1, int cy1, T* __restrict__ gplane, int W,
@@ -641,12 +648,37 @@ __device__ __forceinline__ void flush_scatter_region(const Cell (*win)[WW], int 
   const int w = cx1 - cx0 + 1, h = cy1 - cy0 + 1;
   if (w <= 0 || h <= 0) return;
   const float iw = 1.0f / float(w);
+#if SCSFM_FLUSH_STEP
+  // Cell i of the region (row-major), i = thread, thread + NT, ...: (row, column) advance by the uniform (NT / w, NT % w)
+  // with a carry instead of being divided out per cell, two cells' LDS reads are in flight together, and the global
+  // address is a 32-bit byte offset from the uniform plane base (a scatter plane is far below 4 GiB).
+  const int n = w * h;
+  const int dq = int((float(NT) + 0.5f) * iw), dr = NT - dq * w;  // NT / w, NT % w: exact for 1 <= w <= NT
+  int i = threadIdx.x;
+  int ry = int((float(i) + 0.5f) * iw);  // i / w, exact for the few thousand cells of a window
+  int rx = i - ry * w;
+  const bool wide = ww.rows > WH;
+  auto cell_of = [&](int y, int x) { const int ly = cy0 + y, lx = cx0 + x; return ly * WW + lx + (wide ? wide_adjust<WH>(ww, ly) : 0); };
+  auto dest_of = [&](int y, int x) { return (unsigned(wy0 + cy0 + y) * unsigned(W) + unsigned(wx0 + cx0 + x)) * unsigned(sizeof(T)); };
+  for (; i < n; i += 2 * NT) {
+    int ry2 = ry + dq, rx2 = rx + dr;
+    if (rx2 >= w) { rx2 -= w; ++ry2; }
+    const bool second = i + NT < n;
+    const Cell v0 = (&win[0][0])[cell_of(ry, rx)];
+    const Cell v1 = second ? (&win[0][0])[cell_of(ry2, rx2)] : Cell(0);
+    if (v0 != Cell(0)) atomic_add_at(gplane, dest_of(ry, rx), T(win_value(v0)));
+    if (v1 != Cell(0)) atomic_add_at(gplane, dest_of(ry2, rx2), T(win_value(v1)));
+    ry = ry2 + dq; rx = rx2 + dr;
+    if (rx >= w) { rx -= w; ++ry; }
+  }
+#else
   for (int i = threadIdx.x; i < w * h; i += NT) {
     const int ry = int((float(i) + 0.5f) * iw);  // i / w, exact for the few thousand cells of a window
     const int ly = cy0 + ry, lx = cx0 + (i - ry * w);
     const Cell v = (&win[0][0])[ly * WW + lx + (ww.rows > WH ? wide_adjust<WH>(ww, ly) : 0)];
     if (v != Cell(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), T(win_value(v)));
   }
+#endif
 }
 
 // Where the window of a tile sits: centred on where the tile's centre pixel (ax, ay) lands in the reference

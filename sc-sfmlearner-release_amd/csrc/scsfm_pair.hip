@@ -349,6 +349,17 @@ __device__ __forceinline__ bool spec_valid(const double* __restrict__ sums, cons
   return double(g_geom[0]) * gate_g * sums[9] == double(g_photo[0]) * sums[10];  // products of floats: exact
 }
 
+// What the next forward speculates on (scsfm_pair_desc::hint): the upstream gradients this backward saw -- unless they
+// are not finite (the overflow step of a loss-scaled run: NaN / Inf say nothing about the loop's weights, and a NaN in
+// the hint would make every later forward run its speculative pass for nothing); such a step leaves the hint alone.
+// A ZERO photo gradient is remembered: a run with -p 0 then takes the plain forward from its second step on.
+template <typename T>
+__device__ __forceinline__ void remember_upstream(double* __restrict__ hint, const T* __restrict__ g_photo,
+                                                  const T* __restrict__ g_geom) {
+  const double a = double(g_photo[0]), b = double(g_geom[0]);
+  if (a - a == 0.0 && b - b == 0.0) { hint[0] = a; hint[1] = b; }  // (the differences are NaN for NaN and +-Inf)
+}
+
 // Bit p: the backward has to run its two passes for pair p (its upstream coefficients are not both zero and the
 // speculative forward did not already do the work).  Evaluated once per workgroup, all pairs' loads in flight
 // together; a launch in which no pair needs anything ends here.
@@ -742,7 +753,7 @@ template <typename T>
 __global__ void pairs_pose_reduce_kernel(PairBatch<T> pb, int B, int nblk_geom, const T* __restrict__ K,
                                          const T* __restrict__ g_photo, const T* __restrict__ g_geom, double* __restrict__ hint) {
   const int pair = blockIdx.x / B, b = blockIdx.x - pair * B;
-  if (hint && blockIdx.x == 0 && threadIdx.x == 0) { hint[0] = double(g_photo[0]); hint[1] = double(g_geom[0]); }
+  if (hint && blockIdx.x == 0 && threadIdx.x == 0) remember_upstream(hint, g_photo, g_geom);
   const PairArgs<T>& pa = pb.p[pair];
   const bool spec = spec_valid(pa.sums, g_photo, g_geom);
   pose_reduce_one(b, spec ? int(pa.sums[11]) : nblk_geom, double(pair_scale(pa.sums, g_photo, g_geom)), pa.pose, K, pa.consts,
@@ -886,7 +897,7 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
                                                                  const T* __restrict__ g_geom, double* __restrict__ hint) {
   // The upstream gradients this backward saw are what the next forward speculates on (scsfm_pair_desc::hint; nothing
   // in this launch or before it on the stream reads the two doubles any more: the forward kernels did).
-  if (hint && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { hint[0] = double(g_photo[0]); hint[1] = double(g_geom[0]); }
+  if (hint && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) remember_upstream(hint, g_photo, g_geom);
   // row 0 of the grid is dispatched first: the pose waves (one latency-bound reduction each) start at once and
   // finish under the streaming rows instead of after them
   const int d = (int)blockIdx.y - 1;
@@ -1176,7 +1187,7 @@ template <typename T>
 static int pairs_fwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags, double w_photo,
                      double w_geom, void* stream_) {
   clear_status();
-  if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !K) return SCSFM_ERR_ARG;
+  if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || !K) return SCSFM_ERR_ARG;
   for (int i = 0; i < n; ++i)
     if (!desc_inputs_ok(d[i], H, W) || !d[i].out) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
@@ -1199,7 +1210,7 @@ template <typename T>
 static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags, void* scratch,
                      const T* g_photo, const T* g_geom, bool accumulate, void* stream_) {
   clear_status();
-  if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !K || !g_photo || !g_geom) return SCSFM_ERR_ARG;
+  if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || !K || !g_photo || !g_geom) return SCSFM_ERR_ARG;
   for (int i = 0; i < n; ++i)
     if (!desc_inputs_ok(d[i], H, W) || !d[i].g_tgt_depth || !d[i].g_ref_depth || !d[i].g_pose || (!d[i].gbuf && !scratch))
       return SCSFM_ERR_ARG;
@@ -1301,7 +1312,7 @@ template <typename T>
 static int pairs_bwd_inputs(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,
                             const T* g_photo, const T* g_geom, T* g_K, void* stream_) {
   clear_status();
-  if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !K || !g_photo || !g_geom) return SCSFM_ERR_ARG;
+  if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || !K || !g_photo || !g_geom) return SCSFM_ERR_ARG;
   for (int i = 0; i < n; ++i)
     if (!desc_inputs_ok(d[i], H, W)) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
@@ -1341,7 +1352,7 @@ static int pairs_bwd_inputs(int n, const scsfm_pair_desc* d, int B, int H, int W
 template <typename T>
 static int pair_refinalize(int B, int H, int W, void* ws, T* out, void* stream) {
   clear_status();
-  if (B <= 0 || H < 2 || W < 2 || !ws || !out) return SCSFM_ERR_ARG;
+  if (B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || !ws || !out) return SCSFM_ERR_ARG;
   const PairWs l = pair_ws_layout(B, H, W);
   double* sums = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + l.off_sums);
   hipLaunchKernelGGL((pair_refinalize_kernel<T>), dim3(1), dim3(kWave), 0, (hipStream_t)stream, sums, out);

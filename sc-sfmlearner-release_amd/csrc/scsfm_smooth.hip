@@ -313,7 +313,7 @@ template <typename T>
 static int smooth_multi_fwd(int n, const void* const* depths, const void* const* imgs, int B, int H, int W, void* ws,
                             void* const* edges, T* out, T* total, void* stream_) {
   clear_status();
-  if (n < 0 || B <= 0 || H < 2 || W < 2 || (n > 0 && (!depths || !imgs || !ws || !out))) return SCSFM_ERR_ARG;
+  if (n < 0 || B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || (n > 0 && (!depths || !imgs || !ws || !out))) return SCSFM_ERR_ARG;
   for (int i = 0; i < n; ++i)
     if (!depths[i] || !imgs[i]) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
@@ -337,7 +337,7 @@ template <typename T>
 static int smooth_multi_bwd(int n, const void* const* depths, const void* const* imgs, int B, int H, int W, void* ws,
                             void* const* edges, const T* g_loss, void* const* g_depths, bool accumulate, void* stream_) {
   clear_status();
-  if (n < 0 || B <= 0 || H < 2 || W < 2 || (n > 0 && (!depths || !imgs || !ws || !g_loss || !g_depths)))
+  if (n < 0 || B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || (n > 0 && (!depths || !imgs || !ws || !g_loss || !g_depths)))
     return SCSFM_ERR_ARG;
   for (int i = 0; i < n; ++i)
     if (!depths[i] || !imgs[i]) return SCSFM_ERR_ARG;
@@ -364,7 +364,7 @@ template <typename T>
 static int smooth_multi_bwd_images(int n, const void* const* depths, const void* const* imgs, int B, int H, int W, void* ws,
                                    const T* g_loss, void* const* g_imgs, bool accumulate, void* stream_) {
   clear_status();
-  if (n < 0 || B <= 0 || H < 2 || W < 2 || (n > 0 && (!depths || !imgs || !ws || !g_loss || !g_imgs))) return SCSFM_ERR_ARG;
+  if (n < 0 || B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || (n > 0 && (!depths || !imgs || !ws || !g_loss || !g_imgs))) return SCSFM_ERR_ARG;
   for (int i = 0; i < n; ++i)
     if (!depths[i] || !imgs[i]) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;

@@ -378,6 +378,9 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
 #ifndef SCSFM_WIDE_WINDOW  // tuning knob: 0 = no wide window for incoherent footprints
 #define SCSFM_WIDE_WINDOW 1
 #endif
+#ifndef SCSFM_WIDE_EY  // footprints taller than this many rows take the wide window.  Round 3: 2 * kWinH; round 4: kWinH -- a
+#define SCSFM_WIDE_EY kWinH  // tile whose taps spread over more rows than the window has finds half of them outside it (a direct
+#endif                       // global atomic each) and half of its texels outside the 17 staged rows anyway: -2 %
   // (the wide window needs the lean layout -- its extension rows are the staging regions -- and 32-bit cells)
   constexpr bool kWideOk = SCSFM_WIDE_WINDOW && SCSFM_LEAN_LDS && SCSFM_STAGE_TAPS && kSpec && kSsim && sizeof(T) == 4 && TH == kTileH;
   int wrows = WH;
@@ -390,8 +393,8 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     }
     if (x0 > x1) { x0 = x1 = 0; y0 = y1 = 0; }  // nothing scatters
     const int ex = x1 - x0 + 2, ey = y1 - y0 + 2;  // cells touched (each pixel reaches one past its tap)
-    // a footprint more than twice as tall as the window: the wide window (scsfm_geom.h: WideWin), no staged taps
-    wrows = (kWideOk && ey > 2 * WH) ? WH + 3 * kWideRows : WH;
+    // a footprint taller than SCSFM_WIDE_EY rows: the wide window (scsfm_geom.h: WideWin), no staged taps
+    wrows = (kWideOk && ey > SCSFM_WIDE_EY) ? WH + 3 * kWideRows : WH;
     wx0 = ex <= WW ? x0 - (WW - ex) / 2 : (x0 + x1 + 1) / 2 - WW / 2;
     wy0 = ey <= wrows ? y0 - (wrows - ey) / 2 : (y0 + y1 + 1) / 2 - wrows / 2;
     cx0 = x0 - wx0; cx1 = x1 + 1 - wx0; cy0 = y0 - wy0; cy1 = y1 + 1 - wy0;

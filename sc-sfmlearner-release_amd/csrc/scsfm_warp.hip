@@ -132,7 +132,7 @@ template <typename T>
 static int warp_fwd(int B, int H, int W, const T* img, const T* depth, const T* ref_depth, const T* pose,
                     const T* K, unsigned flags, void* ws, T* o_img, T* o_valid, T* o_pd, T* o_cd, void* stream_) {
   clear_status();
-  if (B <= 0 || H < 2 || W < 2 || !img || !depth || !ref_depth || !pose || !K || !ws || !o_img || !o_valid ||
+  if (B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || !img || !depth || !ref_depth || !pose || !K || !ws || !o_img || !o_valid ||
       !o_pd || !o_cd)
     return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
@@ -150,7 +150,7 @@ static int warp_bwd(int B, int H, int W, const T* img, const T* depth, const T* 
                     const T* K, unsigned flags, void* ws, const T* g_img, const T* g_pd, const T* g_cd,
                     T* g_depth, T* g_ref_depth, T* g_pose, void* stream_) {
   clear_status();
-  if (B <= 0 || H < 2 || W < 2 || !img || !depth || !ref_depth || !pose || !K || !ws || !g_depth || !g_pose)
+  if (B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || !img || !depth || !ref_depth || !pose || !K || !ws || !g_depth || !g_pose)
     return SCSFM_ERR_ARG;
   if (g_pd && !g_ref_depth) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
@@ -175,7 +175,7 @@ template <typename T>
 static int warp_bwd_inputs(int B, int H, int W, const T* depth, const T* pose, const T* K, unsigned flags, void* ws,
                            const T* g_img, T* g_src, T* g_K, void* stream_) {
   clear_status();
-  if (B <= 0 || H < 2 || W < 2 || !pose || !K || !ws || (g_src && (!g_img || !depth))) return SCSFM_ERR_ARG;
+  if (B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || !pose || !K || !ws || (g_src && (!g_img || !depth))) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   auto* consts = reinterpret_cast<BatchConsts<T>*>(ws);
   const int quat = (flags & SCSFM_ROT_QUAT_FLAG) ? 1 : 0;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kThreads) void cam2pixel_bwd_kernel(int H, int W, u
 template <typename T>
 static int pixel2cam_fwd(int B, int H, int W, const T* depth, const T* Kinv, T* cam, void* stream) {
   clear_status();
-  if (B <= 0 || H < 1 || W < 1 || !depth || !Kinv || !cam) return SCSFM_ERR_ARG;
+  if (B <= 0 || H < 1 || W < 1 || !dims_ok<T>(B, H, W) || !depth || !Kinv || !cam) return SCSFM_ERR_ARG;
   dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
   hipLaunchKernelGGL((pixel2cam_fwd_kernel<T>), grid, dim3(kThreads), 0, (hipStream_t)stream, H, W, depth, Kinv, cam);
   return launch_status();
@@ -354,7 +354,7 @@ static int pixel2cam_fwd(int B, int H, int W, const T* depth, const T* Kinv, T* 
 template <typename T>
 static int pixel2cam_bwd(int B, int H, int W, const T* Kinv, const T* g_cam, T* g_depth, void* stream) {
   clear_status();
-  if (B <= 0 || H < 1 || W < 1 || !Kinv || !g_cam || !g_depth) return SCSFM_ERR_ARG;
+  if (B <= 0 || H < 1 || W < 1 || !dims_ok<T>(B, H, W) || !Kinv || !g_cam || !g_depth) return SCSFM_ERR_ARG;
   dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
   hipLaunchKernelGGL((pixel2cam_bwd_kernel<T>), grid, dim3(kThreads), 0, (hipStream_t)stream, H, W, Kinv, g_cam, g_depth);
   return launch_status();
@@ -362,7 +362,7 @@ static int pixel2cam_bwd(int B, int H, int W, const T* Kinv, const T* g_cam, T* 
 template <typename T>
 static int pixel2cam_bwd_intrinsics(int B, int H, int W, const T* depth, const T* g_cam, T* g_Kinv, void* stream) {
   clear_status();
-  if (B <= 0 || H < 1 || W < 1 || !depth || !g_cam || !g_Kinv) return SCSFM_ERR_ARG;
+  if (B <= 0 || H < 1 || W < 1 || !dims_ok<T>(B, H, W) || !depth || !g_cam || !g_Kinv) return SCSFM_ERR_ARG;
   hipLaunchKernelGGL((pixel2cam_bwd_intrinsics_kernel<T>), dim3(B), dim3(kThreads), 0, (hipStream_t)stream, H, W, depth, g_cam,
                      g_Kinv);
   return launch_status();
@@ -371,7 +371,7 @@ template <typename T>
 static int cam2pixel_fwd(int B, int H, int W, const T* cam, const T* rot, const T* tr, unsigned flags, T* grid_out, T* z_out,
                          void* stream) {
   clear_status();
-  if (B <= 0 || H < 2 || W < 2 || !cam || !grid_out) return SCSFM_ERR_ARG;
+  if (B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || !cam || !grid_out) return SCSFM_ERR_ARG;
   dim3 grid(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), B);
   hipLaunchKernelGGL((cam2pixel_fwd_kernel<T>), grid, dim3(kThreads), 0, (hipStream_t)stream, H, W, flags, cam, rot, tr,
                      grid_out, z_out);
@@ -381,7 +381,7 @@ template <typename T>
 static int cam2pixel_bwd(int B, int H, int W, const T* cam, const T* rot, const T* tr, unsigned flags, const T* g_grid,
                          const T* g_z, T* g_cam, double* gP, void* stream_) {
   clear_status();
-  if (B <= 0 || H < 2 || W < 2 || !cam || !g_grid || !g_cam || !gP) return SCSFM_ERR_ARG;
+  if (B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || !cam || !g_grid || !g_cam || !gP) return SCSFM_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   hipError_t e = hipMemsetAsync(gP, 0, (size_t)B * 12 * sizeof(double), stream);
   if (e != hipSuccess) return (int)e;
@@ -417,8 +417,10 @@ int scsfm_abi_version(void) { return 7; }
 #ifndef SCSFM_SOURCE_ID
 #define SCSFM_SOURCE_ID "unknown"
 #endif
+// (behind a marker, so that scsfm_hip/build.py can read the id from the FILE -- a stale binary may not even load)
+static const char g_source_tag[] __attribute__((used)) = "scsfm-source-id:" SCSFM_SOURCE_ID;
 int scsfm_source_id(char* buf, size_t n) {
-  static const char id[] = SCSFM_SOURCE_ID;
+  const volatile char* id = g_source_tag + 16;  // (volatile: the bytes stay in the binary's data, not in immediates)
   if (!buf || n == 0) return SCSFM_ERR_ARG;
   size_t i = 0;
   for (; i + 1 < n && id[i]; ++i) buf[i] = id[i];

@@ -93,32 +93,28 @@ _lib = None
 
 
 def get() -> CLib:
-    """The HIP library (singleton).  Builds it with hipcc on first use if it is not there, and ties the binary to the
-    sources next to it: a library whose compiled-in source hash differs from the tree's is rebuilt, or -- without
-    hipcc -- refused (a library named by SCSFM_HIP_LIB, a tuning variant, is taken as it is)."""
+    """The HIP library (singleton).  Ties the binary to the sources next to it BEFORE loading it: the source id compiled
+    into libscsfm_hip.so is read from the file (scsfm_hip.build.binary_source_id -- a stale binary may lack symbols or
+    carry another ABI number, which the strict loader below would report as an error instead of rebuilding), and a
+    missing or stale library is built with hipcc under a file lock, so that the N ranks of a torchrun job that all
+    arrive here at once compile once.  Without hipcc a stale library is refused.  A library named by SCSFM_HIP_LIB (a
+    tuning variant, a system-wide install) is taken as it is."""
     global _lib
     if _lib is None:
         with _lock:
             if _lib is None:
                 from . import build as _build
                 own = "SCSFM_HIP_LIB" not in os.environ
-                if own and not os.path.exists(LIB_PATH):
-                    _build.build()
+                if own and _build.is_stale():
+                    have = _build.binary_source_id(LIB_PATH)
+                    try:
+                        _build.build()
+                    except Exception as e:
+                        what = f"was built from other sources ({have}) than the tree's ({_build.source_id()})" if have \
+                            else "is missing (or carries no source id)"
+                        raise ScsfmError(f"{LIB_PATH} {what} and cannot be built here: {e}") from e
                 lib = CLib(LIB_PATH)
                 if own and lib.source_id() != _build.source_id():
-                    try:
-                        _build.build(force=True)
-                    except Exception as e:
-                        raise ScsfmError(f"{LIB_PATH} was built from other sources ({lib.source_id()}) than the tree's "
-                                         f"({_build.source_id()}) and cannot be rebuilt here: {e}") from e
-                    # (a shared object cannot be reloaded into the process under the same name: the stale copy stays
-                    # mapped, so the fresh one is opened through a unique temporary link)
-                    import tempfile
-                    link = os.path.join(tempfile.mkdtemp(prefix="scsfm_"), "libscsfm_hip.so")
-                    os.symlink(LIB_PATH, link)
-                    lib = CLib(link)
-                    lib.path = LIB_PATH
-                    if lib.source_id() != _build.source_id():
-                        raise ScsfmError(f"{LIB_PATH}: rebuilt, but its source id {lib.source_id()} is not the tree's")
+                    raise ScsfmError(f"{LIB_PATH}: its source id {lib.source_id()} is not the tree's {_build.source_id()}")
                 _lib = lib
     return _lib

@@ -491,10 +491,13 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         want = list(need_imgs) if need_imgs is not None else [False] * len(imgs)
         g_imgs = [torch.zeros_like(im) if w else None for im, w in zip(imgs, want)]
         g_K = torch.empty_like(K) if need_K else None
-        by_ptr = {im.data_ptr(): g for im, g in zip(imgs, g_imgs)}
-        for j, (ti, ri, *_rest) in enumerate(pairs):
-            descs[j].g_tgt_img = _p(by_ptr[ti.data_ptr()]) or None
-            descs[j].g_ref_img = _p(by_ptr[ri.data_ptr()]) or None
+        # by POSITION in the argument list (key = ("t", s) -> image 0, ("r", i, s) -> image 1 + i), not by storage: the
+        # same tensor passed twice (a reference frame repeated, the target among the references) gets one gradient
+        # per argument, as the reference's autograd would return, and autograd adds them up
+        pos = lambda key: 0 if key[0] == "t" else 1 + key[1]
+        for j, (_ti, _ri, _dt, _dr, _po, kt, kr) in enumerate(pairs):
+            descs[j].g_tgt_img = _p(g_imgs[pos(kt)]) or None
+            descs[j].g_ref_img = _p(g_imgs[pos(kr)]) or None
         lib.call(f"scsfm_pairs_bwd_inputs_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags,
                  _p(g_photo), _p(g_geom), _p(g_K), _stream(tgt_img))
         g_inputs = (g_imgs, g_K)

@@ -17,8 +17,9 @@ def set_weight_hint(w_photo, w_geom):
     """Tell the loss which upstream-gradient ratio to speculate on; ``None, None`` disables it."""
     global _hint
     if w_photo is None:
+        # (the device tensors stay alive: a captured HIP graph may still hold their addresses; hint_tensor() hands
+        # none out while speculation is off)
         _hint = None
-        _hint_dev.clear()
         return
     # the upstream gradients arrive as fp32 tensors: compare against the fp32 roundings of the weights
     # (the device-side check is an exact equality of products)

@@ -49,19 +49,40 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init_process_group_from_env(backend=None):
-    """Initialise torch.distributed for one-process-per-GPU runs launched by torchrun.  Backend
-    defaults to nccl (RCCL) when a GPU is visible, gloo otherwise.  Returns (rank, local_rank, world)."""
+def init_process_group(backend, rank, world, device=None, force=False):
+    """The one place a process group is created (train.py and bench.py both come through here).  ``nccl`` (= RCCL on
+    ROCm) is bound to ``device`` (``device_id``: the communicator is created eagerly on that GPU and collectives never
+    have to guess the device); ``gloo`` serves the CPU tests and ranks that share one GPU.  ``force``: also at world
+    size 1 (bench.py --force-dist).  Rendezvous defaults to 127.0.0.1 (one node; the container's hostname may not
+    resolve).  Returns True when a group was created."""
     import torch.distributed as dist
-    rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+    if (world <= 1 and not force) or dist.is_initialized():
+        return False
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend == "nccl":
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+    else:
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return True
+
+
+def init_process_group_from_env(backend=None):
+    """Initialise torch.distributed for one-process-per-GPU runs launched by torchrun.  Backend defaults to nccl (RCCL)
+    when a GPU is visible, gloo otherwise.  Returns (rank, local_rank, world).  The HIP library is loaded here as well
+    -- and built, once per node under scsfm_hip.build's file lock, if the tree has none -- so that no rank meets a
+    compiler inside its first training step."""
+    rank, local_rank, world = env_world()
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    device = torch.device("cuda", local_rank) if backend == "nccl" else None
+    init_process_group(backend, rank, world, device)
+    if torch.cuda.is_available():
+        from . import _lib
+        _lib.get()
     return rank, local_rank, world
 
 

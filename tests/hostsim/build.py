@@ -11,7 +11,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "sc-sfmlearner-release_amd", "csrc")
-OUT = os.path.join(HERE, "_build")
+# HOSTSIM_EXTRA="-DSCSFM_X=1 ...": a tuning variant of the kernels under the same tests (its objects go to their own
+# directory, so that the default build is not disturbed)
+EXTRA = os.environ.get("HOSTSIM_EXTRA", "").split()
+OUT = os.path.join(HERE, "_build" + ("_" + "".join(c if c.isalnum() else "_" for c in "".join(EXTRA)) if EXTRA else ""))
 LIB = os.path.join(OUT, "libscsfm_hostsim.so")
 
 
@@ -30,6 +33,7 @@ def build(force=False):
         procs.append(subprocess.Popen(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "c++", "-I", HERE,
                                        "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
                                        "-DSCSFM_WITH_MARCH",  # the experimental column-march variant stays testable here
+                                       *EXTRA,
                                        "-c", s, "-o", o]))
     for p in procs:
         if p.wait() != 0:

@@ -66,6 +66,55 @@ def test_product_library_builds_and_exports_every_symbol():
     assert lib.size("scsfm_smooth_ws_bytes", 12, 256, 832) > 0
 
 
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"),
+                    reason="no hipcc on this machine")
+def test_entry_points_reject_sizes_their_32_bit_offsets_cannot_address():
+    """csrc/scsfm_common.h: dims_ok.  The kernels address the three colour planes of one image with 32-bit byte
+    offsets and put (pair, batch element) on the grid's z axis: an image of 3 * H * W * sizeof(T) >= 4 GiB or a batch
+    beyond 8191 is refused with SCSFM_ERR_ARG before anything is launched (so this runs without a GPU; the pointers only
+    have to be non-null)."""
+    import ctypes
+    from scsfm_hip import build, capi
+    lib = _lib.CLib(build.build(verbose=False))
+    buf = ctypes.create_string_buffer(4096)
+    p = ctypes.addressof(buf)
+    big_h, big_w = 20000, 20000          # 3 * 4e8 * 4 B = 4.8 GB per image in fp32
+    assert 3 * big_h * big_w * 4 >= 2 ** 32
+    d = (capi.PairDesc * 1)()
+    for f in ("tgt_img", "ref_img", "tgt_depth", "ref_depth", "pose", "ws", "out", "total"):
+        setattr(d[0], f, p)
+    call = lambda name, *a: lib._fn[name](*a)
+    assert call("scsfm_pairs_fwd_f32", 1, ctypes.addressof(d), 1, big_h, big_w, p, 7, 1.0, 0.5, None) == -1
+    assert call("scsfm_pairs_fwd_f32", 1, ctypes.addressof(d), 8192, 16, 16, p, 7, 1.0, 0.5, None) == -1   # grid z
+    assert call("scsfm_pairs_fwd_f64", 1, ctypes.addressof(d), 1, 16384, 16384, p, 7, 1.0, 0.5, None) == -1  # fp64: 6.4 GB
+    assert call("scsfm_warp_fwd_f32", 1, big_h, big_w, p, p, p, p, p, 0, p, p, p, p, p, None) == -1
+    ptrs = (ctypes.c_void_p * 1)(p)
+    assert call("scsfm_smooth_multi_fwd_f32", 1, ptrs, ptrs, 1, big_h, big_w, p, None, p, None) == -1
+    assert call("scsfm_ssim_fwd_f32", 1, big_h, big_w, p, p, p, None) == -1
+
+
+def test_bench_quotes_hbm_counters_only_for_the_library_they_were_collected_on(tmp_path, monkeypatch):
+    """bench.py: roofline.traffic comes from profiles/pmc_latest.json, which names the library (source id) the
+    rocprofv3 --pmc passes ran on; a different loaded library gets None and the reason, not stale counters."""
+    import argparse
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    key = "scsfm::pair_fwd_spec_kernel<float, true, 7u, false, false>|gz48"
+    json.dump({"_library_source_id": "aaaa", key: {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 24.0}}, open(prof / "pmc_latest.json", "w"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    a = argparse.Namespace(batch=12, height=256, width=832, n_ref=2, depth="smooth")
+    assert bench.pmc_traffic(a, 4, "aaaa")[0] == 1024 * 1024
+    got, why = bench.pmc_traffic(a, 4, "bbbb")
+    assert got is None and "aaaa" in why and "bbbb" in why
+    a.depth = "iid"
+    assert bench.pmc_traffic(a, 4, "aaaa")[0] is None
+
+
 def test_product_loader_never_points_at_the_simulator():
     assert _lib.LIB_PATH.endswith(os.path.join("scsfm_hip", "libscsfm_hip.so"))
     src = open(_lib.__file__).read()

@@ -26,6 +26,10 @@ POSE_RTOL = 1.5e-2
 # rows of 16 beyond 5 %, up to 72 % -- on DIFFERENT rows.  Which rows depends on the last bit of every coordinate, so
 # iid cases are judged by row statistics, not by every entry.
 POSE_RTOL_IID = 3e-2
+# test_depth_gradients_entrywise_away_from_the_gates: HIP's worst judged entry against the fp32 reference arithmetic's
+ENTRYWISE_MAX_FACTOR = 2.0
+# test_iid_pose_gradients_as_row_statistics_over_seeds: HIP's row errors against the fp32 reference arithmetic's
+IID_ROW_FACTOR = 2.0
 FLAGS = [(1, 1, 1), (1, 1, 0), (1, 0, 1), (1, 0, 0), (0, 1, 1), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
 
 
@@ -148,6 +152,7 @@ def test_pose_and_errors_goldens(LF, IW, dev):
     (3, 100, 210, 1, "kitti", "iid", 1, "zeros", 1),        # ragged: partial tiles
     (12, 256, 832, 2, "kitti", "smooth", 1, "zeros", 1),    # configs[1] / [2] per-GPU workload
     (4, 256, 320, 4, "nyu", "smooth", 1, "zeros", 1),       # configs[4]: NYU intrinsics, 4 refs
+    (16, 256, 320, 4, "nyu", "smooth", 1, "zeros", 1),      # ... at the batch SURVEY 8 fixes for it (scripts/train_nyu.sh:7)
     (8, 256, 832, 2, "kitti", "smooth", 1, "zeros", 1),     # configs[3]: batch 8 per GPU
     (4, 256, 832, 2, "kitti", "iid", 1, "zeros", 1),        # full size, incoherent gathers / scatter
     (4, 256, 832, 2, "kitti", "smooth", 1, "border", 1),    # full size, border padding
@@ -191,8 +196,9 @@ def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto, 
         rel = lambda x, c: (x - c).abs().max(dim=1).values / c.abs().max(dim=1).values
         rows_h = torch.cat([rel(gh[i], g64[i]) for i in range(n_ref + 1, 3 * n_ref + 1)])
         rows_o = torch.cat([rel(go[i], g64[i]) for i in range(n_ref + 1, 3 * n_ref + 1)])
-        assert float(rows_h.median()) <= max(POSE_RTOL, 3 * float(rows_o.median())), (rows_h, rows_o)
-        assert float((rows_h > 0.05).double().mean()) <= 0.3, rows_h
+        # (one seed, a handful of rows: the median only; the distribution over four seeds -- median, 90 % quantile and
+        # maximum against the reference's own fp32 arithmetic -- is test_iid_pose_gradients_as_row_statistics_over_seeds)
+        assert float(rows_h.median()) <= IID_ROW_FACTOR * float(rows_o.median()) + POSE_RTOL, (rows_h, rows_o)
     for i, (a, b, c) in enumerate(zip(gh, go, g64)):
         scale = float(c.abs().max())
         if i <= n_ref or i > 3 * n_ref:   # depth maps: entry-wise with a small share of outliers (flipped pixels)
@@ -682,7 +688,7 @@ def test_depth_gradients_entrywise_away_from_the_gates(LF, dev, B, depth, pad):
 
     Every entry of the three depth gradients of compute_photo_and_geometry_loss whose value cannot hinge on a gate
     decided within fp32 round-off (oracle.pairwise_gate_margins, evaluated in fp64; >= 92 % of the entries) must lie
-    within 0.3 % of the tensor's largest entry of the fp64 oracle's value (10 % on iid inputs) -- the entries set aside
+    within twice the worst such entry of the reference's own fp32 arithmetic in the same run -- the entries set aside
     are off by up to a third of it, in the reference's own fp32 arithmetic as much as here (measured,
     tools/diag_gates.py) -- and the error distribution over those entries (median, 99 %, 99.9 %) must be no wider than
     twice that of the reference's fp32 arithmetic against the same fp64 values.  (fp32 against fp64 cannot be asked
@@ -708,7 +714,6 @@ def test_depth_gradients_entrywise_away_from_the_gates(LF, dev, B, depth, pad):
     v64, g64 = run("cpu", O.photo_and_geometry_loss, torch.float64)
     assert abs(vh[0] - v64[0]) <= 1e-5 and abs(vh[1] - v64[1]) <= 1e-5, (vh, v64)
     unsafe = _unsafe_maps(O, d, n_ref, pad)
-    cap = 1e-1 if depth == "iid" else 3e-3  # (iid: measured 5.8e-2 at the worst judged entry, 1.4e-1 among those set aside)
     for i, (a, o, c, u) in enumerate(zip(gh, g32, g64, unsafe)):
         a, o, c = a[:, 0], o[:, 0], c[:, 0]
         keep = ~u
@@ -721,7 +726,9 @@ def test_depth_gradients_entrywise_away_from_the_gates(LF, dev, B, depth, pad):
               f"p99.9 {qh[2]:.2e} max {float(eh.max()):.2e} | reference fp32 {qo[0]:.2e} {qo[1]:.2e} {qo[2]:.2e} max {float(eo.max()):.2e} "
               f"| set aside: hip max {float(((a - c).abs() / scale)[u].max()):.2e}")
         assert share >= 0.92, (i, share)
-        assert float(eh.max()) <= cap, (i, float(eh.max()))
+        # the worst judged entry: no further from fp64 than ENTRYWISE_MAX_FACTOR x the worst entry of the reference's own
+        # fp32 arithmetic in this very run (round 3 used constants: 3e-3, and 1e-1 on iid inputs)
+        assert float(eh.max()) <= ENTRYWISE_MAX_FACTOR * float(eo.max()) + 1e-6, (i, float(eh.max()), float(eo.max()))
         for x, y in zip(qh, qo):
             assert x <= 2 * y + 1e-7, (i, qh, qo)
 
@@ -861,3 +868,92 @@ def test_inputs_at_odd_element_offsets_give_the_same_results(dev, LF):
             assert torch.equal(a, b)
         for a, b in zip(got[3:], ref[3:]):
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------
+# 8. round 4: the reference's call structure under anomaly mode; iid pose gradients as row statistics over seeds
+# ------------------------------------------------------------------------------------------------
+def test_reference_call_structure_under_anomaly_mode(LF, dev):
+    """The reference switches torch.autograd.set_detect_anomaly(True) on globally (train.py:67) and its loop makes
+    three calls, a weighted sum and backward() (train.py:259-282).  The drop-in's autograd nodes must survive that mode
+    -- it checks every gradient a node returns for NaN and keeps forward tracebacks -- with a pair whose mask is below
+    the 10000-pixel gate (loss_functions.py:123-129: the term is a constant 0 there) in the batch, at configs[1] size,
+    and give the very same numbers as without it."""
+    from scsfm_hip import synth
+    d = synth.make_batch(12, 256, 832, n_ref=2, seed=23, depth="smooth", image="smooth", dataset="kitti")
+    # the second reference view is thrown far off: next to none of its pixels land inside the image in either direction
+    d["poses"][1] = d["poses"][1].clone(); d["poses_inv"][1] = d["poses_inv"][1].clone()
+    d["poses"][1][:, 0] = 500.0; d["poses_inv"][1][:, 0] = -500.0
+    to = lambda t: t.to(dev)
+    tgt, K, refs = to(d["tgt_img"]), to(d["intrinsics"]), [to(t) for t in d["ref_imgs"]]
+    w1, w2, w3 = 1.0, 0.1, 0.5
+
+    def step():
+        mv = lambda t: t.to(dev).clone().requires_grad_(True)
+        td, rd = [mv(d["tgt_depth"][0])], [[mv(r[0])] for r in d["ref_depths"]]
+        ps, pi = [mv(p) for p in d["poses"]], [mv(p) for p in d["poses_inv"]]
+        photo, geom = LF.compute_photo_and_geometry_loss(tgt, refs, K, td, rd, ps, pi, 1, 1, 1, 1, "zeros")
+        smooth = LF.compute_smooth_loss(td, tgt, rd, refs)
+        loss = w1 * photo + w2 * smooth + w3 * geom
+        loss.backward()
+        leaves = td + [r[0] for r in rd] + ps + pi
+        assert all(bool(torch.isfinite(t.grad).all()) for t in leaves)
+        return [float(loss.detach()), float(photo.detach()), float(smooth.detach()), float(geom.detach())], \
+            [t.grad.clone() for t in leaves]
+
+    v0, g0 = step()
+    # the thrown-off pairs are below the gate: their terms are zero (single-pair call, same inputs)
+    p1, q1 = LF.compute_pairwise_loss(tgt, refs[1], to(d["tgt_depth"][0]), to(d["ref_depths"][1][0]), to(d["poses"][1]), K,
+                                      1, 1, 1, "zeros")
+    assert float(p1) == 0.0 and float(q1) == 0.0
+    assert float(g0[5].abs().max()) == 0.0 and float(g0[7].abs().max()) == 0.0   # ... and so are their poses' gradients
+    assert float(g0[4].abs().max()) > 0.0
+    prev = torch.is_anomaly_enabled()
+    torch.autograd.set_detect_anomaly(True)
+    try:
+        v1, g1 = step()
+        v2, g2 = step()
+    finally:
+        torch.autograd.set_detect_anomaly(prev)
+    assert v0[1:] == v1[1:] == v2[1:], (v0, v1, v2)        # bit-reproducible forward
+    for a, b, c in zip(g0, g1, g2):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-12 and float((a - c).abs().max()) <= 1e-5 * scale + 1e-12
+
+
+def test_iid_pose_gradients_as_row_statistics_over_seeds(LF, dev):
+    """Pose gradients on iid inputs (independent depths 0.1 .. 100 per pixel: a handful of near pixels carry d/d
+    translation, and one gate that rounds the other way moves a row by per cents -- in ANY fp32 evaluation, the
+    reference's own included, and on different rows in different implementations).  Judged as a distribution, pooled
+    over four seeds at 4 x 256 x 832 (64 rows): the HIP path's row errors against the fp64 oracle must be no larger
+    than IID_ROW_FACTOR x those of the fp32 oracle (= the reference's arithmetic) against the same fp64 values, at the
+    median, at the 90 % quantile and at the maximum, plus 1.5 % of the row's scale."""
+    from oracle import scsfm_oracle as O
+    from scsfm_hip import synth
+    B, H, W, n_ref = 4, 256, 832, 2
+    rows_h, rows_o = [], []
+    for seed in (17, 18, 19, 20):
+        d = synth.make_batch(B, H, W, n_ref=n_ref, seed=seed, depth="iid", image="iid", dataset="kitti")
+
+        def run(device, fn_pg, dtype):
+            mv = lambda t: t.to(device=device, dtype=dtype).clone().requires_grad_(True)
+            cv = lambda t: t.to(device=device, dtype=dtype)
+            td, rd = [mv(d["tgt_depth"][0])], [[mv(r[0])] for r in d["ref_depths"]]
+            ps, pi = [mv(p) for p in d["poses"]], [mv(p) for p in d["poses_inv"]]
+            photo, geom = fn_pg(cv(d["tgt_img"]), [cv(r) for r in d["ref_imgs"]], cv(d["intrinsics"]), td, rd, ps, pi, 1, 1, 1, 1, "zeros")
+            (photo + 0.5 * geom).backward()
+            return [p.grad.detach().cpu().double() for p in ps + pi]
+
+        gh = run(dev, LF.compute_photo_and_geometry_loss, torch.float32)
+        go = run("cpu", O.photo_and_geometry_loss, torch.float32)
+        g64 = run("cpu", O.photo_and_geometry_loss, torch.float64)
+        rel = lambda x, c: (x - c).abs().max(dim=1).values / c.abs().max(dim=1).values
+        rows_h += [rel(a, c) for a, c in zip(gh, g64)]
+        rows_o += [rel(b, c) for b, c in zip(go, g64)]
+    rh, ro = torch.cat(rows_h), torch.cat(rows_o)
+    stat = lambda t: (float(t.median()), float(torch.quantile(t, 0.9)), float(t.max()))
+    sh, so = stat(rh), stat(ro)
+    print(f"iid pose rows (n = {rh.numel()}): hip median {sh[0]:.4f} p90 {sh[1]:.4f} max {sh[2]:.4f} | "
+          f"reference fp32 median {so[0]:.4f} p90 {so[1]:.4f} max {so[2]:.4f}")
+    for x, y in zip(sh, so):
+        assert x <= IID_ROW_FACTOR * y + POSE_RTOL, (sh, so)

@@ -627,6 +627,11 @@ def test_the_device_side_hint_follows_the_upstream_gradients(lib):
         # sums[8]: still a valid speculation after the backward (1) or retired by the fallback (0)
         held.append([float(_sums_of(lib, ws, j, B, H, W)[8]) for j in range(2)])
     assert held == [[0.0, 0.0], [1.0, 1.0], [1.0, 1.0]], held
+    # a backward whose upstream gradients are not finite (the overflow step of a loss-scaled run) leaves the hint alone
+    for bad in (float("nan"), float("inf")):
+        photo, geom, _, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=(1.0, 0.5), hint_dev=hint_dev)
+        capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, t(bad), t(0.3), hint_dev=hint_dev)
+        assert hint_dev.tolist() == [1.0, 0.3]
     # a backward with a zero photometric weight: nothing to factor out next time, the forward says so itself
     photo, geom, _, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=(1.0, 0.5), hint_dev=hint_dev)
     capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, t(0.0), t(0.7), hint_dev=hint_dev)

@@ -66,6 +66,30 @@ def test_photo_geometry_gradients_of_images_and_intrinsics(lib, flags3, pad, hin
     assert res[4][0] is None and res[4][2] is None and res[5] is None and _rel(res[4][1], ris[0].grad) < 1e-10
 
 
+def test_the_same_image_passed_twice_gets_one_gradient_per_argument(lib):
+    """A reference frame repeated (or the target among the references): the gradient buffers are keyed by the
+    argument's POSITION, so each occurrence receives its own gradient and autograd's sum over the occurrences is the
+    oracle's gradient of the shared tensor (keyed by storage, the later occurrence used to take the earlier one's)."""
+    x = _batch(3, 40, 92, seed=11)
+    shared = x["ris"][0]
+    ris_x = [shared, shared]                        # the SAME storage as both references
+    ti, K, r = leaf(x["ti"]), leaf(x["K"]), leaf(shared)
+    td, rd = [leaf(t) for t in x["tds"]], [[leaf(t) for t in rr] for rr in x["rds"]]
+    pp, pi = [leaf(p) for p in x["ps"]], [leaf(p) for p in x["pis"]]
+    po, go = O.photo_and_geometry_loss(ti, [r, r], K, td, rd, pp, pi, 1, 1, 1, 1, "zeros")
+    (0.7 * po + 1.3 * go).backward()
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    _, _, _, ws = capi.photo_geometry_fwd(lib, fl, x["ti"], x["K"], ris_x, x["tds"], x["rds"], x["ps"], x["pis"], hint=(0.7, 1.3))
+    t = lambda v: torch.tensor([v], dtype=torch.float64)
+    res = capi.photo_geometry_bwd(lib, fl, x["ti"], x["K"], ris_x, x["tds"], x["rds"], x["ps"], x["pis"], ws, t(0.7), t(1.3),
+                                  need_imgs=[True, True, True], need_K=False)
+    g_imgs = res[4]
+    assert g_imgs[1].data_ptr() != g_imgs[2].data_ptr()
+    assert float(g_imgs[1].abs().max()) > 0 and float(g_imgs[2].abs().max()) > 0
+    assert _rel(g_imgs[1] + g_imgs[2], r.grad) < 1e-10
+    assert _rel(g_imgs[0], ti.grad) < 1e-10
+
+
 def test_single_pair_entry_points_give_the_same_input_gradients(lib):
     x = _batch(7, 40, 92, seed=9, n_ref=1)
     ti, ri, K = leaf(x["ti"]), leaf(x["ris"][0]), leaf(x["K"])

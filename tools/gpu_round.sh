@@ -27,6 +27,11 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/prof_$TAG -o pmc_iid_$C -- python $R/bench.py --loss-steps 3 --loss-warmup 1 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 2 --depth iid > $O/rocprof_${TAG}_iid_$C.log 2>&1; echo "rc=$?"
 done
 cd $R
+# the counters, tied to the library they were collected on (bench.py quotes profiles/pmc_latest.json only for that library)
+SID=$(python -c "import sys; sys.path.insert(0, 'sc-sfmlearner-release_amd'); from scsfm_hip import _lib; print(_lib.get().source_id())" 2>/dev/null | tail -n 1)
+python tools/pmc_summary.py $O/prof_$TAG --json $O/pmc_$TAG.json --source-id "$SID" > $O/pmc_$TAG.txt 2>&1
+python tools/pmc_summary.py $O/prof_$TAG --prefix pmc_iid_ --json $O/pmc_${TAG}_iid.json --source-id "$SID" > $O/pmc_${TAG}_iid.txt 2>&1
+head -4 $O/pmc_$TAG.txt
 python tools/rocprof_summary.py $O/prof_$TAG/trace_results.db | grep -v "at::native\|rocclr" | head -20
 bash tools/gpu_sq.sh $TAG > $O/sq_$TAG.txt 2>&1; tail -14 $O/sq_$TAG.txt
 echo "=== stage timeline of the tile kernel (PROBE_TIMING build) and the column-march variant for the record"

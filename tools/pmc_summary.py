@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """Per-kernel FETCH_SIZE / WRITE_SIZE (KiB per dispatch) from rocprofv3 --pmc runs (rocpd databases).
     python tools/pmc_summary.py gpurun_out/prof_TAG   ->  text;  --json FILE also writes a machine-readable summary;
-    --prefix pmc_iid_ reads the passes of another workload (tools/gpu_round.sh: iid depth)"""
+    --prefix pmc_iid_ reads the passes of another workload (tools/gpu_round.sh: iid depth);
+    --source-id ID records which library (scsfm_source_id) the passes ran on"""
 import json
 import os
 import sqlite3
 import sys
 
 
-def main(d, json_out=None, prefix="pmc_"):
+def main(d, json_out=None, prefix="pmc_", source_id=None):
     res = {}
+    if source_id:  # which library the counters were collected on: bench.py only quotes them for that very library
+        res["_library_source_id"] = source_id
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         path = os.path.join(d, f"{prefix}{c}_results.db")
         if not os.path.exists(path):
@@ -36,9 +39,13 @@ def main(d, json_out=None, prefix="pmc_"):
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    pre = "pmc_"
+    pre, sid = "pmc_", None
     if "--prefix" in a:
         i = a.index("--prefix")
         pre = a[i + 1]
         del a[i:i + 2]
-    main(a[0], a[2] if len(a) > 2 and a[1] == "--json" else None, pre)
+    if "--source-id" in a:
+        i = a.index("--source-id")
+        sid = a[i + 1]
+        del a[i:i + 2]
+    main(a[0], a[2] if len(a) > 2 and a[1] == "--json" else None, pre, sid)

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""One tuning variant (SCSFM_HIP_LIB=variants/X.so) on the bench workload: kernel-only time of the speculative forward
+(smooth and iid depth) and, for comparing variants with each other, the step's losses and gradient checksums.
+    SCSFM_HIP_LIB=variants/f1.so python tools/variant_check.py [--iters 40] [--rounds 2]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "sc-sfmlearner-release_amd"))
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    for k, v in (("batch", 12), ("height", 256), ("width", 832), ("n_ref", 2), ("iters", 40), ("rounds", 2)):
+        ap.add_argument("--" + k.replace("_", "-"), type=int, default=v)
+    ap.add_argument("--dataset", default="kitti")
+    ap.add_argument("--depths", default="smooth,iid")
+    a = ap.parse_args()
+    from scsfm_hip import _lib, capi
+    import loss_functions as LF
+    lib = _lib.get()
+    dev = torch.device("cuda:0")
+    out = {"lib": os.path.basename(lib.path), "us": {}, "check": {}}
+    for depth in a.depths.split(","):
+        a.depth = depth
+        x, _ = bench.make_inputs(a, 0, dev)
+        loss, photo, smooth, geom = bench.hot_path_step(LF, x, (1, 1, 1, "zeros"))
+        gs = [x["tgt_depth"][0].grad] + [r[0].grad for r in x["ref_depths"]]
+        ps = x["poses"] + x["poses_inv"]
+        out["check"][depth] = {"photo": float(photo), "geom": float(geom),
+                               "gd_sum": [float(g.double().sum()) for g in gs], "gd_abs": [float(g.double().abs().sum()) for g in gs],
+                               "gpose": [float(p.grad.double().abs().sum()) for p in ps]}
+        det = lambda t: t.detach()
+        tgt, K, refs = x["tgt_img"], x["K"], x["ref_imgs"]
+        tds, rds = [det(x["tgt_depth"][0])], [[det(r[0])] for r in x["ref_depths"]]
+        pp, pis = [det(p) for p in x["poses"]], [det(p) for p in x["poses_inv"]]
+        fl = capi.make_flags(1, 1, 1, "zeros")
+        _, _, _, ws = capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, pp, pis, hint=(1.0, 0.5))
+        fn = lambda: capi.photo_geometry_fwd(lib, fl | 16384, tgt, K, refs, tds, rds, pp, pis, hint=(1.0, 0.5), ws=ws)
+        out["us"][depth] = [round(bench._event_time(fn, a.iters) * 1e6, 1) for _ in range(a.rounds)]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
