@@ -61,7 +61,7 @@ extern "C" {
  * buffers (2: the batched backwards store their depth gradients; scratch holds six planes.  3: scsfm_smooth_multi_bwd
  * takes `accumulate`; scsfm_step_total / scsfm_step_weights; scsfm_pair_desc::total.  4: scsfm_pixel2cam_*, scsfm_cam2pixel_*,
  * SCSFM_ROT_QUAT_FLAG for the warp entry points.  5: scsfm_pair_desc::depth_shift.  6: scsfm_pair_desc::hint,
- * scsfm_source_id.  7: gradients of the data inputs -- scsfm_pair_desc::g_tgt_img / g_ref_img, scsfm_pairs_bwd_inputs,
+ * scsfm_source_id.  8: scsfm_pairs_bwd_smooth, scsfm_smooth_multi_fwd_step.  7: gradients of the data inputs -- scsfm_pair_desc::g_tgt_img / g_ref_img, scsfm_pairs_bwd_inputs,
  * scsfm_warp_bwd_inputs, scsfm_pixel2cam_bwd_intrinsics, scsfm_masked_mean_bwd_mask, scsfm_smooth_multi_bwd_images). */
 int scsfm_abi_version(void);
 /* Identity of the sources this binary was built from: the first 16 hex digits of the sha256 over csrc/ and this header
@@ -183,6 +183,21 @@ int scsfm_pairs_fwd_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, co
 int scsfm_pairs_bwd_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, const double* intrinsics,
                         unsigned flags, void* scratch, const double* g_photo, const double* g_geom,
                         void* stream);
+
+/* The same backward with the smooth loss's gradient riding along (ABI 8; loss_functions.py:132-159 next to :50-92, as
+ * train.py:262-268 combines them): frame_grads[j] -- one of the full-resolution depth-gradient buffers the descriptors
+ * name -- additionally receives g_smooth[0] * d smooth_j / d depth_j in the very pass that stores it, instead of being
+ * re-read and re-written by scsfm_smooth_multi_bwd.  frame_edges[j]: the edge plane scsfm_smooth_multi_fwd left for
+ * frame j; frame_stats[j]: the first 2 * B doubles of frame j's smooth workspace ({mean + 1e-7, loss} per image).
+ * n_frames <= 16; a frame whose buffer no descriptor names is an argument error. */
+int scsfm_pairs_bwd_smooth_f32(int n, const scsfm_pair_desc* d, int B, int H, int W, const float* intrinsics,
+                               unsigned flags, void* scratch, const float* g_photo, const float* g_geom, int n_frames,
+                               void* const* frame_grads, void* const* frame_edges, void* const* frame_stats,
+                               const float* g_smooth, void* stream);
+int scsfm_pairs_bwd_smooth_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, const double* intrinsics,
+                               unsigned flags, void* scratch, const double* g_photo, const double* g_geom, int n_frames,
+                               void* const* frame_grads, void* const* frame_edges, void* const* frame_stats,
+                               const double* g_smooth, void* stream);
 
 /* Gradients of the DATA inputs of the pair losses.  The reference's autograd reaches the images (the target image
  * through the L1 and SSIM terms, loss_functions.py:99-108; the reference image through grid_sample's input,
@@ -337,6 +352,15 @@ int scsfm_masked_mean_bwd_mask_f64(int B, int C, int Cm, int HW, const double* d
  * written per pixel) instead of re-evaluating the edge weights from the images. */
 int scsfm_smooth_multi_fwd_f32(int n, const void* const* depths, const void* const* imgs, int B, int H,
                                int W, void* ws, void* const* edges, float* out, void* stream);
+/* ... and, in the launch that finishes the frames' total, the step's objective (train.py:268) from it and the pair losses
+ * computed before (ABI 8): photo_geom[2] = {photo, geometry} (device) -> step_out[4] = {w_photo photo + w_smooth smooth +
+ * w_geom geometry, photo, smooth, geometry} (device, store), instead of a launch of scsfm_step_total.  n <= 8. */
+int scsfm_smooth_multi_fwd_step_f32(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,
+                                    void* ws, void* const* edges, float* out, const float* photo_geom, double w_photo,
+                                    double w_smooth, double w_geom, float* step_out, void* stream);
+int scsfm_smooth_multi_fwd_step_f64(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,
+                                    void* ws, void* const* edges, double* out, const double* photo_geom, double w_photo,
+                                    double w_smooth, double w_geom, double* step_out, void* stream);
 int scsfm_smooth_multi_bwd_f32(int n, const void* const* depths, const void* const* imgs, int B, int H,
                                int W, void* ws, void* const* edges, const float* g_loss,
                                void* const* g_depths, int accumulate, void* stream);

@@ -597,15 +597,19 @@ __device__ __forceinline__ int wide_adjust(const WideWin& ww, int ly) {  // only
   return e >= 0 ? ww.off + r * ww.step : 0;
 }
 
+// inv_unit (the fallback geometry pass): the window counts in units of 1 / inv_unit -- that pass scatters values that
+// already carry the 1e-7-sized factor of the masked mean, far below the fixed-point cells' resolution, so it stages
+// g * inv_unit (inv_unit = 1 / max(|a|, |b|) of its pair: magnitudes as in the speculative forward) and its flush
+// multiplies the cells by the unit again; taps that bypass the window add the unscaled g.
 template <typename T, typename Cell, int WW, int WH>
 __device__ __forceinline__ void scatter_taps_window(Cell (*win)[WW], int wx0, int wy0,
                                                     T* __restrict__ gplane, const Sample<T>& s, T g,
-                                                    const WideWin& ww = WideWin{WH, 0, 0}) {
+                                                    const WideWin& ww = WideWin{WH, 0, 0}, T inv_unit = T(1)) {
   if (g == T(0)) return;
   const int lx = s.xa - wx0, ly = s.ya - wy0;
-  if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < ww.rows - 1 && win_fits(&win[0][0], g)) {
+  if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < ww.rows - 1 && win_fits(&win[0][0], g * inv_unit)) {
     // unpredicated: a cell of the block that is not a tap has weight 0, and adding 0 leaves it at the 0 the flush skips
-    const T gu = win_unit(&win[0][0], g);
+    const T gu = win_unit(&win[0][0], g * inv_unit);
     Cell* rn = &win[0][0] + ly * WW + lx;
     Cell* rs = rn + WW;
     if (ww.rows > WH) { rn += wide_adjust<WH>(ww, ly); rs += wide_adjust<WH>(ww, ly + 1); }  // (uniform branch)
@@ -621,11 +625,11 @@ __device__ __forceinline__ void scatter_taps_window(Cell (*win)[WW], int wx0, in
 // Only cells that received an in-image tap are non-zero, so every flushed cell is a valid pixel.
 template <typename T, typename Cell, int WW, int WH>
 __device__ __forceinline__ void flush_scatter_window(const Cell (*win)[WW], int wx0, int wy0,
-                                                     T* __restrict__ gplane, int W) {
+                                                     T* __restrict__ gplane, int W, T unit = T(1)) {
   for (int i = threadIdx.x; i < WW * WH; i += kThreads) {
     const int ly = i / WW, lx = i - ly * WW;
     const Cell v = win[ly][lx];
-    if (v != Cell(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), T(win_value(v)));
+    if (v != Cell(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), T(win_value(v)) * unit);
   }
 }
 
@@ -794,7 +798,8 @@ __device__ __forceinline__ void fwd_taps(const Sample<T>& s, bool staged, int fx
 template <typename T, typename Cell, int WW, int WH>
 __device__ __forceinline__ T geom_consume(const BatchConsts<T>& bc, const GeomTaps<T>& f, int px, int py, T d, const T (&gI)[3], T g_dd,
                                           int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
-                                          T* __restrict__ scatter_plane, T* acc, const WideWin& ww = WideWin{WH, 0, 0}) {
+                                          T* __restrict__ scatter_plane, T* acc, const WideWin& ww = WideWin{WH, 0, 0},
+                                          T inv_unit = T(1)) {
   const Sample<T>& s = f.s;
   const TapRows<T>(&tc)[3] = f.tc;
   const TapRows<T>& td = f.td;
@@ -817,16 +822,17 @@ __device__ __forceinline__ T geom_consume(const BatchConsts<T>& bc, const GeomTa
   t.s.b = gI[0] * tc[0].s.b + gI[1] * tc[1].s.b + gI[2] * tc[2].s.b + gDp * td.s.b;
   T gix, giy;
   tap_rows_grad(t, s, gix, giy);
-  if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, Cell, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp, ww);
+  if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, Cell, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp, ww, inv_unit);
   return pixel_geometry_bwd(bc, s, px, py, d, gix, giy, gZ, H, W, acc);
 }
 template <typename T, typename Cell, int WW, int WH, typename Map>
 __device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py, T d, const T (&gI)[3], T g_dd,
                                         const T* __restrict__ ref_img, const Map& ref_depth,
                                         unsigned plane, int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
-                                        T* __restrict__ scatter_plane, T* acc) {
+                                        T* __restrict__ scatter_plane, T* acc, T inv_unit = T(1)) {
   const GeomTaps<T> f = geom_fetch(bc, px, py, d, ref_img, ref_depth, plane, H, W, flags);
-  return geom_consume<T, Cell, WW, WH>(bc, f, px, py, d, gI, g_dd, H, W, flags, win, wx0, wy0, scatter_plane, acc);
+  return geom_consume<T, Cell, WW, WH>(bc, f, px, py, d, gI, g_dd, H, W, flags, win, wx0, wy0, scatter_plane, acc,
+                                       WideWin{WH, 0, 0}, inv_unit);
 }
 
 }  // namespace scsfm

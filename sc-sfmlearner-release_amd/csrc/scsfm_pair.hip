@@ -638,11 +638,16 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
   double* __restrict__ gP = pa.gPp;
   constexpr int ROWS = kGeomRows;  // pixels per thread: a block covers a 64 x (4 ROWS) tile
   __shared__ double red[12 * (kThreads / kWave)];
-  // (cells in the working type: this pass runs with the final coefficients, ~1e-5 in magnitude, for which the
-  // fixed-point cells of the speculative forward -- whose values are unscaled -- are too coarse)
-  typedef T Cell;
+  // Fixed-point cells, as in the speculative forward (an LDS float atomic serialises per lane on gfx950: the float
+  // window of rounds 1-3 cost this pass 5 us per tile), counted in units of the pair's own coefficient: this pass runs
+  // with the FINAL coefficients a = g_photo / (3 S_m), b = g_geom / S_m (~1e-7), so the values it stages are divided by
+  // max(|a|, |b|) -- magnitudes of a few units, like the speculative forward's unscaled terms -- and the flush
+  // multiplies the cells by it again.  fp64 (gradient checks): floating cells, unit 1.
+  typedef typename WinCell<T>::type Cell;
   __shared__ Cell win[kWinH][kWinW];  // staging window of the scatter into dL/d ref_depth
   if (T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0)) return;  // as in pass A
+  const T ca = t_abs(T(sums[5]) * g_photo[0]), cb_ = t_abs(T(sums[6]) * g_geom[0]);
+  const T unit = sizeof(T) == 4 ? (ca > cb_ ? ca : cb_) : T(1), inv_unit = T(1) / unit;
   if (spec_valid(sums, g_photo, g_geom)) return;  // the speculative forward already ran this pass in its tail
   const int px = blk.x * kWave + (threadIdx.x & (kWave - 1));
   const int py0 = (blk.y * (kThreads / kWave) + threadIdx.x / kWave) * ROWS;
@@ -685,11 +690,11 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
     if (px >= W || py >= H) continue;
     const T gI[3] = {in_g[r][0], in_g[r][1], in_g[r][2]};
     const T gd = geom_pixel<T, Cell, kWinW, kWinH>(bc, px, py, in_d[r], gI, in_g[r][3], ref_img, ref_depth, plane, H, W, flags,
-                                             win, wx0, wy0, g_scatter, acc);
+                                             win, wx0, wy0, g_scatter, acc, inv_unit);
     st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), (flags & SCSFM_DEBUG_X2) ? T(0) : gd);
   }
   __syncthreads();
-  if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5))) flush_scatter_window<T, Cell, kWinW, kWinH>(win, wx0, wy0, g_scatter, W);
+  if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5))) flush_scatter_window<T, Cell, kWinW, kWinH>(win, wx0, wy0, g_scatter, W, unit);
   if (flags & SCSFM_DEBUG_X3) {  // profiling: keep the partials defined
     if (threadIdx.x == 0)
       for (int i = 0; i < 12; ++i) gP[12 * ((size_t)(b * nby + blk.y) * nbx + blk.x) + i] = 0.0;
@@ -805,7 +810,26 @@ struct CombineBatch {
   int nd, nsrc;
   CombineSrc<T> src[2 * kMaxPairs];  // sorted by dst: the sources of dst d are src[first[d] .. first[d] + count[d])
   int first[2 * kMaxPairs], count[2 * kMaxPairs];
+  // scsfm_pairs_bwd_smooth: the smooth loss's gradient of the same map rides along (loss_functions.py:132-159; what
+  // smooth_bwd_kernel would add in a launch of its own, re-reading and re-writing the map): dst += g_smooth *
+  // (edge * (1 / den_b) - L_b / (den_b^2 H W)) with edge = the plane the smooth forward left and per_img = its
+  // {den_b, L_b} records.  nullptr: nothing to add.
+  const T* sm_edge[2 * kMaxPairs];
+  const double* sm_img[2 * kMaxPairs];
+  const T* g_smooth;
 };
+// Per-image constants of the smooth term of destination d for image b: v = e * c.x - c.y.
+template <typename T>
+struct SmoothCoef { T x, y; };
+template <typename T>
+__device__ __forceinline__ SmoothCoef<T> smooth_coef(const CombineBatch<T>& cb, int d, int b, size_t plane) {
+  SmoothCoef<T> c;
+  const double den = cb.sm_img[d][2 * b], L = cb.sm_img[d][2 * b + 1];
+  const T g = cb.g_smooth[0];
+  c.x = g * T(1.0 / den);
+  c.y = g * T(L / (den * den * (double)plane));
+  return c;
+}
 
 template <typename T>
 struct alignas(16) Quad { T v[16 / sizeof(T)]; };  // 16-byte vector access
@@ -836,8 +860,9 @@ __device__ __forceinline__ bool combine_sources(const CombineBatch<T>& cb, int d
 // written) is replaced by a live one with weight 0, so that no load sits behind a branch; returns false (nothing done)
 // when no source is live and the general loop should store the zeros.
 template <typename T, int NS>
-__device__ __forceinline__ bool combine_quads(const CombineBatch<T>& cb, int d, size_t nq, bool store,
-                                              const T* __restrict__ g_photo, const T* __restrict__ g_geom) {
+__device__ __forceinline__ bool combine_quads(const CombineBatch<T>& cb, int d, size_t q0, size_t nq, bool store,
+                                              const T* __restrict__ g_photo, const T* __restrict__ g_geom, bool smooth,
+                                              SmoothCoef<T> sm) {
   constexpr int Q = 16 / sizeof(T);
   const Quad<T>* p[NS];
   T sc[NS];
@@ -855,12 +880,16 @@ __device__ __forceinline__ bool combine_quads(const CombineBatch<T>& cb, int d, 
 #pragma unroll
   for (int j = 0; j < NS; ++j) p[j] = sc[j] != T(0) ? p[j] : safe;
   Quad<T>* __restrict__ out = reinterpret_cast<Quad<T>*>(cb.dst[d]);
-  const size_t stride = (size_t)gridDim.x * kThreads;
-  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  for (; i + stride < nq; i += 2 * stride) {
-    Quad<T> x[2][NS], o[2];
+  // (without a smooth term the edge loads read a live plane with weight 0: no load behind a branch)
+  const Quad<T>* __restrict__ pe = smooth ? reinterpret_cast<const Quad<T>*>(cb.sm_edge[d]) : safe;
+  const T ex = smooth ? sm.x : T(0), ey = smooth ? sm.y : T(0);
+  const size_t stride = (size_t)gridDim.x * kThreads, end = q0 + nq;
+  size_t i = q0 + (size_t)blockIdx.x * kThreads + threadIdx.x;
+  for (; i + stride < end; i += 2 * stride) {
+    Quad<T> x[2][NS], o[2], e[2];
 #pragma unroll
     for (int j = 0; j < NS; ++j) { x[0][j] = p[j][i]; x[1][j] = p[j][i + stride]; }
+    e[0] = pe[i]; e[1] = pe[i + stride];
     if (!store) { o[0] = out[i]; o[1] = out[i + stride]; }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -871,10 +900,12 @@ __device__ __forceinline__ bool combine_quads(const CombineBatch<T>& cb, int d, 
       for (int j = 0; j < NS; ++j)
 #pragma unroll
         for (int q = 0; q < Q; ++q) acc.v[q] += sc[j] * x[h][j].v[q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) acc.v[q] += ex * e[h].v[q] - ey;
       out[i + h * stride] = acc;
     }
   }
-  for (; i < nq; i += stride) {
+  for (; i < end; i += stride) {
     Quad<T> acc;
 #pragma unroll
     for (int q = 0; q < Q; ++q) acc.v[q] = T(0);
@@ -885,6 +916,9 @@ __device__ __forceinline__ bool combine_quads(const CombineBatch<T>& cb, int d, 
 #pragma unroll
       for (int q = 0; q < Q; ++q) acc.v[q] += sc[j] * x.v[q];
     }
+    const Quad<T> e = pe[i];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc.v[q] += ex * e.v[q] - ey;
     out[i] = acc;
   }
   return true;
@@ -897,11 +931,12 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
                                                                  const T* __restrict__ g_geom, double* __restrict__ hint) {
   // The upstream gradients this backward saw are what the next forward speculates on (scsfm_pair_desc::hint; nothing
   // in this launch or before it on the stream reads the two doubles any more: the forward kernels did).
-  if (hint && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) remember_upstream(hint, g_photo, g_geom);
+  if (hint && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) remember_upstream(hint, g_photo, g_geom);
   // row 0 of the grid is dispatched first: the pose waves (one latency-bound reduction each) start at once and
   // finish under the streaming rows instead of after them
   const int d = (int)blockIdx.y - 1;
   if (d < 0) {  // the pose row
+    if (blockIdx.z != 0) return;
     const int item = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
     if (item < npairs * B) {
       const int pair = item / B, b = item - pair * B;
@@ -915,25 +950,33 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
   }
   if (cb.ds[d]) return;  // a coarser scale's map: pairs_combine_pooled_kernel
   constexpr int Q = 16 / sizeof(T);
+  // one image of the batch per blockIdx.z: the smooth term's per-image constants are workgroup-uniform
+  const int b = blockIdx.z;
+  const size_t plane = n / (size_t)B, e0 = (size_t)b * plane;
   T* __restrict__ dst = cb.dst[d];
   const bool store = cb.store[d] != 0;
+  const bool smooth = cb.sm_edge[d] != nullptr;
+  SmoothCoef<T> sm;
+  sm.x = T(0); sm.y = T(0);
+  if (smooth) sm = smooth_coef(cb, d, b, plane);
   const T* src[2 * kMaxPairs];
   T scale[2 * kMaxPairs];
-  const bool aligned = combine_sources(cb, d, g_photo, g_geom, src, scale);
-  // 16-byte accesses over the part every plane has 16-byte aligned (n is a multiple of Q for every image size
-  // in use; the scalar loop below takes whatever is left)
-  const size_t nq = aligned ? n / Q : 0;
+  bool aligned = combine_sources(cb, d, g_photo, g_geom, src, scale);
+  aligned = aligned && (plane % Q) == 0 && (!smooth || (reinterpret_cast<size_t>(cb.sm_edge[d]) & 15) == 0);
+  // 16-byte accesses where every plane (and an image's first element in it) is 16-byte aligned; the scalar loop below
+  // takes whatever is left
+  const size_t nq = aligned ? plane / Q : 0, q0 = aligned ? e0 / Q : 0;
   // The usual shapes -- a map with 2 .. 4 sources (the dense plane of the pairs it is the target of, the scatter plane
   // of those that sampled it) -- run with every load of a thread's two quads in flight together (combine_quads);
   // anything else takes the general loop.
   bool done = false;
   switch (cb.count[d]) {
-    case 2: done = combine_quads<T, 2>(cb, d, nq, store, g_photo, g_geom); break;
-    case 3: done = combine_quads<T, 3>(cb, d, nq, store, g_photo, g_geom); break;
-    case 4: done = combine_quads<T, 4>(cb, d, nq, store, g_photo, g_geom); break;
+    case 2: done = combine_quads<T, 2>(cb, d, q0, nq, store, g_photo, g_geom, smooth, sm); break;
+    case 3: done = combine_quads<T, 3>(cb, d, q0, nq, store, g_photo, g_geom, smooth, sm); break;
+    case 4: done = combine_quads<T, 4>(cb, d, q0, nq, store, g_photo, g_geom, smooth, sm); break;
     default: break;
   }
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; !done && i < nq; i += (size_t)gridDim.x * kThreads) {
+  for (size_t i = q0 + (size_t)blockIdx.x * kThreads + threadIdx.x; !done && i < q0 + nq; i += (size_t)gridDim.x * kThreads) {
     Quad<T> acc;
 #pragma unroll
     for (int j = 0; j < Q; ++j) acc.v[j] = T(0);
@@ -945,6 +988,11 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
         for (int j = 0; j < Q; ++j) acc.v[j] += scale[k] * x.v[j];
       }
     }
+    if (smooth) {
+      const Quad<T> e = reinterpret_cast<const Quad<T>*>(cb.sm_edge[d])[i];
+#pragma unroll
+      for (int j = 0; j < Q; ++j) acc.v[j] += sm.x * e.v[j] - sm.y;
+    }
     if (!store) {
       const Quad<T> o = reinterpret_cast<const Quad<T>*>(dst)[i];
 #pragma unroll
@@ -952,11 +1000,12 @@ __global__ __launch_bounds__(kThreads) void pairs_combine_kernel(CombineBatch<T>
     }
     reinterpret_cast<Quad<T>*>(dst)[i] = acc;
   }
-  for (size_t i = nq * Q + (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) {
+  for (size_t i = e0 + nq * Q + (size_t)blockIdx.x * kThreads + threadIdx.x; i < e0 + plane; i += (size_t)gridDim.x * kThreads) {
     T acc = T(0);
 #pragma unroll
     for (int k = 0; k < 2 * kMaxPairs; ++k)
       if (scale[k] != T(0)) acc += scale[k] * src[k][i];
+    if (smooth) acc += sm.x * cb.sm_edge[d][i] - sm.y;
     dst[i] = store ? acc : dst[i] + acc;
   }
 }
@@ -1206,11 +1255,31 @@ static int pairs_fwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
   return SCSFM_OK;
 }
 
+// `sm` (scsfm_pairs_bwd_smooth): the smooth loss's gradient of n_frames depth maps is added by the same combining pass
+// that stores them -- frame j's gradient buffer must be one of the buffers the descriptors name (g_tgt_depth /
+// g_ref_depth at depth_shift 0).
+struct SmoothFrames {
+  int n = 0;
+  void* const* grads = nullptr;       // [n] depth-gradient buffers
+  void* const* edges = nullptr;       // [n] edge planes left by scsfm_smooth_multi_fwd
+  void* const* per_img = nullptr;     // [n] {den_b, L_b} records = the start of each frame's smooth workspace
+  const void* g_smooth = nullptr;     // 1 element
+};
 template <typename T>
 static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags, void* scratch,
-                     const T* g_photo, const T* g_geom, bool accumulate, void* stream_) {
+                     const T* g_photo, const T* g_geom, bool accumulate, void* stream_, const SmoothFrames& sm = SmoothFrames()) {
   clear_status();
   if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || !K || !g_photo || !g_geom) return SCSFM_ERR_ARG;
+  if (sm.n < 0 || sm.n > 2 * kMaxPairs || (sm.n > 0 && (!sm.grads || !sm.edges || !sm.per_img || !sm.g_smooth || (flags & SCSFM_DEBUG_SKIP_GEOM))))
+    return SCSFM_ERR_ARG;
+  for (int j = 0; j < sm.n; ++j) {  // every frame's buffer must be a full-resolution destination of this call
+    if (!sm.grads[j] || !sm.edges[j] || !sm.per_img[j]) return SCSFM_ERR_ARG;
+    bool found = false;
+    for (int i = 0; i < n && !found; ++i)
+      found = d[i].depth_shift == 0 && (d[i].g_tgt_depth == sm.grads[j] || d[i].g_ref_depth == sm.grads[j]);
+    if (!found) return SCSFM_ERR_ARG;
+  }
+  bool sm_done[2 * kMaxPairs] = {};
   for (int i = 0; i < n; ++i)
     if (!desc_inputs_ok(d[i], H, W) || !d[i].g_tgt_depth || !d[i].g_ref_depth || !d[i].g_pose || (!d[i].gbuf && !scratch))
       return SCSFM_ERR_ARG;
@@ -1260,6 +1329,8 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
       // target depth map, its scatter plane to its reference depth map
       CombineBatch<T> cb;
       cb.nd = 0; cb.nsrc = 0;
+      cb.g_smooth = (const T*)sm.g_smooth;
+      for (int k = 0; k < 2 * kMaxPairs; ++k) { cb.sm_edge[k] = nullptr; cb.sm_img[k] = nullptr; }
       for (int i = 0; i < m; ++i) {
         for (int which = 0; which < 2; ++which) {
           T* dst = (T*)(which == 0 ? d[i0 + i].g_tgt_depth : d[i0 + i].g_ref_depth);
@@ -1272,6 +1343,12 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
             while (q < nseen && seen[q] != dst) ++q;
             cb.store[k] = (!accumulate && q == nseen && nseen < kSeenMax) ? 1 : 0;
             if (q == nseen && nseen < kSeenMax) seen[nseen++] = dst;
+            for (int j = 0; j < sm.n; ++j)  // the smooth term joins the first combining pass that writes this buffer
+              if (sm.grads[j] == (void*)dst && !sm_done[j] && d[i0 + i].depth_shift == 0) {
+                cb.sm_edge[k] = (const T*)sm.edges[j]; cb.sm_img[k] = (const double*)sm.per_img[j];
+                sm_done[j] = true;
+                break;
+              }
             ++cb.nd;
           }
           CombineSrc<T>& sc = cb.src[cb.nsrc++];
@@ -1292,14 +1369,15 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
         for (int q = 0; q < cb.nsrc; ++q) cb.src[q] = sorted[q];
         for (int k = cb.nd; k < 2 * kMaxPairs; ++k) { cb.first[k] = 0; cb.count[k] = 0; }
       }
-      int gx = (int)((npx + 8 * kThreads - 1) / (8 * kThreads));
+      // one image of the batch per grid z (8 elements per thread); row 0 of y: dL/dpose, on z = 0
+      const size_t plane = (size_t)H * W;
+      int gx = (int)((plane + 8 * kThreads - 1) / (8 * kThreads));
       const int gpose = ceil_div(m * B, kThreads / kWave);
       gx = gx < gpose ? gpose : gx;
-      // (+ 1 row of workgroups: dL/dpose)
-      hipLaunchKernelGGL((pairs_combine_kernel<T>), dim3(gx, cb.nd + 1), dim3(kThreads), 0, stream, cb, npx, pb, m, B,
+      hipLaunchKernelGGL((pairs_combine_kernel<T>), dim3(gx, cb.nd + 1, B), dim3(kThreads), 0, stream, cb, npx, pb, m, B,
                          nbx * nby, K, g_photo, g_geom, (double*)d[0].hint);
       if (!full_res)
-        hipLaunchKernelGGL((pairs_combine_pooled_kernel<T>), dim3(gx / 4 + 1, cb.nd), dim3(kThreads), 0, stream, cb, npx, W,
+        hipLaunchKernelGGL((pairs_combine_pooled_kernel<T>), dim3((int)((npx + 8 * kThreads - 1) / (8 * kThreads)) / 4 + 1, cb.nd), dim3(kThreads), 0, stream, cb, npx, W,
                            g_photo, g_geom);
     }
   }
@@ -1430,6 +1508,14 @@ size_t scsfm_pair_ws_bytes(int B, int H, int W) {
   int scsfm_pairs_bwd_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,          \
                             void* scratch, const T* g_photo, const T* g_geom, void* stream) {                         \
     return scsfm::pairs_bwd<T>(n, d, B, H, W, K, flags, scratch, g_photo, g_geom, false, stream);                     \
+  }                                                                                                                   \
+  int scsfm_pairs_bwd_smooth_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,   \
+                                   void* scratch, const T* g_photo, const T* g_geom, int n_frames,                    \
+                                   void* const* frame_grads, void* const* frame_edges, void* const* frame_stats,      \
+                                   const T* g_smooth, void* stream) {                                                 \
+    scsfm::SmoothFrames sm;                                                                                           \
+    sm.n = n_frames; sm.grads = frame_grads; sm.edges = frame_edges; sm.per_img = frame_stats; sm.g_smooth = g_smooth; \
+    return scsfm::pairs_bwd<T>(n, d, B, H, W, K, flags, scratch, g_photo, g_geom, false, stream, sm);                 \
   }                                                                                                                   \
   int scsfm_pairs_bwd_inputs_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,   \
                                    const T* g_photo, const T* g_geom, T* g_intrinsics, void* stream) {                \

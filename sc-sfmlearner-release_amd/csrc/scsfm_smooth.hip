@@ -59,6 +59,12 @@ struct SmoothBatch {
   unsigned* counter;  // in the first frame's workspace; zeroed by the forward kernel
   T* total;           // nullptr: not wanted
   int first;          // 1: store (first launch of the call), 0: add
+  // scsfm_smooth_multi_fwd_step: the block that finishes the frames' total also forms the step's objective
+  // (train.py:268) from it and the pair losses the caller computed before -- step_out[4] = {w1 photo + w2 smooth + w3
+  // geometry, photo, smooth, geometry} -- instead of a launch of its own (scsfm_step_total)
+  const T* step_pg;   // {photo, geometry} (device), or nullptr
+  T* step_out;
+  T w1, w2, w3;
 };
 
 template <typename T>
@@ -180,6 +186,11 @@ __global__ __launch_bounds__(kThreads) void smooth_finalize_kernel(SmoothBatch<T
         T sum = T(0);
         for (unsigned i = 0; i < gridDim.x; ++i) sum += *const_cast<const volatile T*>(sb.f[i].out);
         sb.total[0] = sb.first ? sum : sb.total[0] + sum;
+        if (sb.step_pg) {
+          const T photo = sb.step_pg[0], geom = sb.step_pg[1], smooth = sb.total[0];
+          sb.step_out[0] = sb.w1 * photo + sb.w2 * smooth + sb.w3 * geom;
+          sb.step_out[1] = photo; sb.step_out[2] = smooth; sb.step_out[3] = geom;
+        }
       }
     }
   }
@@ -311,8 +322,10 @@ static SmoothFrame<T> make_frame(int B, int H, int W, const void* depth, const v
 
 template <typename T>
 static int smooth_multi_fwd(int n, const void* const* depths, const void* const* imgs, int B, int H, int W, void* ws,
-                            void* const* edges, T* out, T* total, void* stream_) {
+                            void* const* edges, T* out, T* total, void* stream_, const T* step_pg = nullptr,
+                            double w1 = 0, double w2 = 0, double w3 = 0, T* step_out = nullptr) {
   clear_status();
+  if (step_pg && (!step_out || !total || n > kMaxFrames)) return SCSFM_ERR_ARG;  // (one launch: the total is complete)
   if (n < 0 || B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || (n > 0 && (!depths || !imgs || !ws || !out))) return SCSFM_ERR_ARG;
   for (int i = 0; i < n; ++i)
     if (!depths[i] || !imgs[i]) return SCSFM_ERR_ARG;
@@ -327,6 +340,7 @@ static int smooth_multi_fwd(int n, const void* const* depths, const void* const*
     sb.counter = reinterpret_cast<unsigned*>((char*)ws + (size_t)i0 * l.total + l.off_counter);
     sb.total = total;
     sb.first = i0 == 0 ? 1 : 0;
+    sb.step_pg = step_pg; sb.step_out = step_out; sb.w1 = T(w1); sb.w2 = T(w2); sb.w3 = T(w3);
     hipLaunchKernelGGL((smooth_fwd_kernel<T>), dim3(l.fbx, l.fby, m * B), dim3(kThreads), 0, stream, sb, B, H, W);
     hipLaunchKernelGGL((smooth_finalize_kernel<T>), dim3(m), dim3(kThreads), 0, stream, sb, B, H, W, l.fbx * l.fby);
   }
@@ -349,7 +363,7 @@ static int smooth_multi_bwd(int n, const void* const* depths, const void* const*
     for (int i = 0; i < m; ++i)
       sb.f[i] = make_frame<T>(B, H, W, depths[i0 + i], imgs[i0 + i], (char*)ws + (size_t)(i0 + i) * l.total, nullptr,
                               g_depths[i0 + i], edges ? edges[i0 + i] : nullptr);
-    sb.counter = nullptr; sb.total = nullptr; sb.first = 0;
+    sb.counter = nullptr; sb.total = nullptr; sb.first = 0; sb.step_pg = nullptr; sb.step_out = nullptr;
     if (accumulate)
       hipLaunchKernelGGL((smooth_bwd_kernel<T, true>), dim3(l.nbx, l.nby, m * B), dim3(kThreads), 0, stream, sb, B, H, W,
                          g_loss);
@@ -375,7 +389,7 @@ static int smooth_multi_bwd_images(int n, const void* const* depths, const void*
     for (int i = 0; i < m; ++i)
       sb.f[i] = make_frame<T>(B, H, W, depths[i0 + i], imgs[i0 + i], (char*)ws + (size_t)(i0 + i) * l.total, nullptr,
                               g_imgs[i0 + i], nullptr);
-    sb.counter = nullptr; sb.total = nullptr; sb.first = 0;
+    sb.counter = nullptr; sb.total = nullptr; sb.first = 0; sb.step_pg = nullptr; sb.step_out = nullptr;
     hipLaunchKernelGGL((smooth_bwd_images_kernel<T>), dim3(ceil_div(W, kWave), ceil_div(H, kThreads / kWave), m * B),
                        dim3(kThreads), 0, stream, sb, B, H, W, g_loss, accumulate ? 1 : 0);
   }
@@ -395,6 +409,13 @@ size_t scsfm_smooth_ws_bytes(int B, int H, int W) {
   int scsfm_smooth_multi_fwd_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,   \
                                    void* ws, void* const* edges, T* out, void* stream) {                             \
     return scsfm::smooth_multi_fwd<T>(n, depths, imgs, B, H, W, ws, edges, out, n > 0 ? out + n : nullptr, stream);   \
+  }                                                                                                                  \
+  int scsfm_smooth_multi_fwd_step_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H,     \
+                                        int W, void* ws, void* const* edges, T* out, const T* photo_geom,           \
+                                        double w_photo, double w_smooth, double w_geom, T* step_out, void* stream) { \
+    if (n <= 0 || !photo_geom || !step_out) return SCSFM_ERR_ARG;                                                    \
+    return scsfm::smooth_multi_fwd<T>(n, depths, imgs, B, H, W, ws, edges, out, out + n, stream, photo_geom, w_photo, \
+                                      w_smooth, w_geom, step_out);                                                   \
   }                                                                                                                  \
   int scsfm_smooth_multi_bwd_##SUF(int n, const void* const* depths, const void* const* imgs, int B, int H, int W,   \
                                    void* ws, void* const* edges, const T* g_loss, void* const* g_depths,             \

@@ -435,13 +435,16 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
 
 
 def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws, g_photo,
-                       g_geom, hint_dev=None, need_imgs=None, need_K=False):
+                       g_geom, hint_dev=None, need_imgs=None, need_K=False, smooth=None):
     """Gradients of photo_geometry_fwd's two sums: (g_tgt_depths[s], g_ref_depths[i][s], g_poses[i],
     g_poses_inv[i]).  Each depth map's gradient buffer receives the sum over every pair-direction that
     touches it (dense as target, scattered as reference) from the library's combining kernel, which
     stores (no zero-fill); one call into the library, one shared scratch buffer.
     ``need_imgs`` (one bool per image: target, then the references) / ``need_K``: also the gradients of the data inputs
-    -> two more results, ([g_tgt_img, g_ref_imgs...] with None where not wanted, g_K)."""
+    -> two more results, ([g_tgt_img, g_ref_imgs...] with None where not wanted, g_K).
+    ``smooth`` = (sws, g_smooth): the workspace of smooth_multi_fwd over the frames [tgt, refs...] at scale 0 (edge
+    planes kept) and the smooth term's upstream gradient -> its gradient is added to the scale-0 depth gradients by the
+    same combining pass that stores them (scsfm_pairs_bwd_smooth), no smooth_multi_bwd launch."""
     B, _, H, W = tgt_img.shape
     pairs = _pair_list(tgt_img, ref_imgs, tgt_depths, ref_depths, poses, poses_inv)
     n = len(pairs)
@@ -482,8 +485,21 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         d.gbuf = wp + j * stride + ws_bytes if spec else None
         d.g_tgt_depth, d.g_ref_depth, d.g_pose = gbuf(kt).data_ptr(), gbuf(kr).data_ptr(), gp + j * psz
         d.depth_shift = _pair_shift(dt, dr, B, H, W)
-    lib.call(f"scsfm_pairs_bwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags, _p(scratch),
-             _p(g_photo), _p(g_geom), _stream(tgt_img))
+    if smooth is not None:
+        sws, g_smooth = smooth
+        nf = 1 + len(ref_depths)
+        sw_bytes = _sizes(lib, B, H, W)[2]
+        plane_bytes = ((B * H * W * tgt_img.element_size() + 255) // 256) * 256
+        assert sws.numel() == nf * (sw_bytes + plane_bytes), "smooth workspace without edge planes"
+        frames = [g_td[0]] + [r[0] for r in g_rd]
+        grads = _ptr_array(frames)
+        edges = (_ct.c_void_p * nf)(*[sws.data_ptr() + nf * sw_bytes + i * plane_bytes for i in range(nf)])
+        stats = (_ct.c_void_p * nf)(*[sws.data_ptr() + i * sw_bytes for i in range(nf)])
+        lib.call(f"scsfm_pairs_bwd_smooth_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags, _p(scratch),
+                 _p(g_photo), _p(g_geom), nf, grads, edges, stats, _p(g_smooth), _stream(tgt_img))
+    else:
+        lib.call(f"scsfm_pairs_bwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags, _p(scratch),
+                 _p(g_photo), _p(g_geom), _stream(tgt_img))
     g_inputs = None
     if need_imgs is not None or need_K:
         # gradients of the data inputs (scsfm_pairs_bwd_inputs): images accumulate, intrinsics are stored
@@ -519,7 +535,7 @@ def _ptr_array(tensors):
     return arr
 
 
-def smooth_multi_fwd(lib, depths, imgs, keep_edges=True):
+def smooth_multi_fwd(lib, depths, imgs, keep_edges=True, step=None):
     """compute_smooth_loss (loss_functions.py:154-159): sum over frames -> (loss, ws).  With
     ``keep_edges`` the forward also leaves every pixel's summed edge terms behind ``ws`` (one fp plane per
     frame) and the backward becomes a pure stream."""
@@ -534,6 +550,12 @@ def smooth_multi_fwd(lib, depths, imgs, keep_edges=True):
     ws = torch.empty(n * (ws_bytes + plane_bytes), dtype=torch.uint8, device=imgs[0].device)
     outs = torch.empty(n + 1, dtype=imgs[0].dtype, device=imgs[0].device)  # one loss per frame, then their sum
     edges = (_ct.c_void_p * n)(*[ws.data_ptr() + n * ws_bytes + i * plane_bytes for i in range(n)]) if keep_edges else None
+    if step is not None:  # (photo_geom[2], w_photo, w_smooth, w_geom): the step's objective in the same launch
+        pg, w1, w2, w3 = step
+        step_out = torch.empty(4, dtype=imgs[0].dtype, device=imgs[0].device)
+        lib.call(f"scsfm_smooth_multi_fwd_step_{_suffix(imgs[0])}", n, _ptr_array(depths), _ptr_array(imgs), B, H, W, _p(ws),
+                 edges, _p(outs), _p(pg), float(w1), float(w2), float(w3), _p(step_out), _stream(imgs[0]))
+        return outs[n], ws, step_out
     lib.call(f"scsfm_smooth_multi_fwd_{_suffix(imgs[0])}", n, _ptr_array(depths), _ptr_array(imgs), B, H, W, _p(ws),
              edges, _p(outs), _stream(imgs[0]))
     return outs[n], ws

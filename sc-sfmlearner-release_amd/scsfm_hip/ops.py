@@ -175,10 +175,11 @@ class StepLoss(torch.autograd.Function):
                                                      poses_inv, group=_dist.exact_group(), hint=hint)
         frames = [tgt_depths[0]] + [r[0] for r in ref_depths]
         imgs = [tgt_img] + list(ref_imgs)
-        smooth, sws = capi.smooth_multi_fwd(lib, frames, imgs, keep_edges=any(ctx.needs_input_grad))
-        # (photo, geom) are elements 0 and 1 of one contiguous row -- the library's totals, or the exact mode's sums
+        # (photo, geom) are elements 0 and 1 of one contiguous row -- the library's totals, or the exact mode's sums;
+        # the smooth forward's finalize launch also forms the weighted sum (no scsfm_step_total launch)
         assert geom.data_ptr() == photo.data_ptr() + photo.element_size()
-        out = capi.step_total(lib, photo, smooth, w_photo, w_smooth, w_geom)
+        smooth, sws, out = capi.smooth_multi_fwd(lib, frames, imgs, keep_edges=any(ctx.needs_input_grad),
+                                                 step=(photo, w_photo, w_smooth, w_geom))
         ctx.cfg = (flags, n_ref, n_scales, w_photo, w_smooth, w_geom)
         ctx.save_for_backward(tgt_img, K, *rest, ws, sws)
         loss, photo_o, smooth_o, geom_o = out[0], out[1], out[2], out[3]
@@ -196,13 +197,14 @@ class StepLoss(torch.autograd.Function):
         gw = capi.step_weights(lib, _scalar(g_loss, tgt_img), w_photo, w_smooth, w_geom)
         need_imgs = [ctx.needs_input_grad[6]] + list(ctx.needs_input_grad[8:8 + n_ref])
         need_K = ctx.needs_input_grad[7]
+        # the smooth term's depth gradients ride along in the pass that stores the pair terms' (scsfm_pairs_bwd_smooth)
         res = capi.photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws,
-                                      gw[0:1], gw[1:2], need_imgs=need_imgs if any(need_imgs) else None, need_K=need_K)
+                                      gw[0:1], gw[1:2], need_imgs=need_imgs if any(need_imgs) else None, need_K=need_K,
+                                      smooth=(sws, gw[2:3]))
         g_td, g_rd, g_poses, g_poses_inv = res[:4]
         g_imgs, g_K = res[4:] if len(res) > 4 else ([None] * (1 + n_ref), None)
         frames = [tgt_depths[0]] + [r[0] for r in ref_depths]
         imgs = [tgt_img] + list(ref_imgs)
-        capi.smooth_multi_bwd(lib, frames, imgs, sws, gw[2:3], into=[g_td[0]] + [r[0] for r in g_rd])
         if any(need_imgs):  # (the data inputs: the smooth term reaches the images through its edge weights)
             capi.smooth_multi_bwd_images(lib, frames, imgs, sws, gw[2:3], need_imgs, into=g_imgs)
         return (None,) * 6 + (g_imgs[0], g_K, *g_imgs[1:], *g_td, *[g for r in g_rd for g in r], *g_poses, *g_poses_inv)

@@ -32,6 +32,9 @@ EXPECTED = {
     "scsfm_pixel2cam_bwd_intrinsics_f32", "scsfm_pixel2cam_bwd_intrinsics_f64",
     "scsfm_masked_mean_bwd_mask_f32", "scsfm_masked_mean_bwd_mask_f64",
     "scsfm_smooth_multi_bwd_images_f32", "scsfm_smooth_multi_bwd_images_f64",
+    # ABI 8: the smooth loss's depth gradients added by the pair backward's combining pass
+    "scsfm_pairs_bwd_smooth_f32", "scsfm_pairs_bwd_smooth_f64",
+    "scsfm_smooth_multi_fwd_step_f32", "scsfm_smooth_multi_fwd_step_f64",
 }
 
 

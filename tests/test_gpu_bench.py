@@ -46,7 +46,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["variants"]) >= 3
     assert {v["threads"] for v in cb["variants"]} >= {1} and any(v["anomaly_mode"] for v in cb["variants"])
     lib = r["library"]
-    assert lib["path"].endswith("scsfm_hip/libscsfm_hip.so") and lib["abi_version"] == 7 and not lib["env_override"]
+    assert lib["path"].endswith("scsfm_hip/libscsfm_hip.so") and lib["abi_version"] == 8 and not lib["env_override"]
     # the binary names the sources it was built from, and they are the tree's
     assert lib["source_id_in_binary"] == lib["source_sha256_16"] and len(lib["source_sha256_16"]) == 16
     assert r["collective_backend"] is None and r["rccl_ranks"] == 1

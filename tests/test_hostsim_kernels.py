@@ -586,6 +586,50 @@ def test_single_node_step_equals_the_three_reference_style_calls(lib, monkeypatc
         assert _rel(b.grad, a.grad) < 1e-11
 
 
+@pytest.mark.parametrize("H,W,dtype,hint,upstream", [
+    (72, 100, torch.float64, (1.0, 0.5), (1.0, 0.5)),    # speculation holds: guards + combine
+    (15, 63, torch.float64, (1.0, 0.5), (0.3, 1.1)),     # odd plane (945 elements: no 16-byte path), fallback passes
+    (33, 129, torch.float32, (1.0, 0.5), (1.0, 0.5)),    # fp32, plane not a multiple of 4
+    (40, 92, torch.float32, None, (0.7, 1.3)),           # fp32, 16-byte path, plain forward
+])
+def test_smooth_gradient_rides_along_in_the_combining_pass(lib, H, W, dtype, hint, upstream):
+    """scsfm_pairs_bwd_smooth (ABI 8): the smooth term's depth gradients added by the pass that stores the pair terms'
+    must equal scsfm_pairs_bwd followed by scsfm_smooth_multi_bwd(accumulate) -- the same additions in another order, so
+    to round-off -- for every frame, on the 16-byte and the scalar paths, after a speculative and after a plain forward."""
+    B = 3
+    d = synth.make_batch(B, H, W, n_ref=2, seed=7, depth="smooth")
+    c = lambda x: x.to(dtype).contiguous()
+    ti, K, ris = c(d["tgt_img"]), c(d["intrinsics"]), [c(r) for r in d["ref_imgs"]]
+    tds, rds = [c(d["tgt_depth"][0])], [[c(r[0])] for r in d["ref_depths"]]
+    ps, pis = [c(p) for p in d["poses"]], [c(p) for p in d["poses_inv"]]
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    t = lambda v: torch.tensor([v], dtype=dtype)
+    frames, imgs = [tds[0]] + [r[0] for r in rds], [ti] + ris
+    _, sws = capi.smooth_multi_fwd(lib, frames, imgs, keep_edges=True)
+    gs = t(0.37)
+
+    def run(fused):
+        _, _, _, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=hint)
+        res = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, t(upstream[0]), t(upstream[1]),
+                                      smooth=(sws, gs) if fused else None)
+        g_td, g_rd, g_p, g_pi = res[:4]
+        if not fused:
+            capi.smooth_multi_bwd(lib, frames, imgs, sws, gs, into=[g_td[0]] + [r[0] for r in g_rd])
+        return [g_td[0].clone()] + [r[0].clone() for r in g_rd] + [x.clone() for x in g_p + g_pi]
+
+    a, b = run(True), run(False)
+    tol = 1e-12 if dtype == torch.float64 else 2e-6
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert k >= 3 or float(y.abs().max()) > 0   # (the small case is below the 10000-pixel gate: its pair terms are 0)
+        assert float((x - y).abs().max()) <= tol * max(float(y.abs().max()), 1e-30)
+    # ... and the smooth part alone is what it should be: fused minus a pair-only backward
+    _, _, _, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=hint)
+    res = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, t(upstream[0]), t(upstream[1]))
+    only = capi.smooth_multi_bwd(lib, frames, imgs, sws, gs)
+    for x, y, z in zip(a[:3], [res[0][0]] + [r[0] for r in res[1]], only):
+        assert _rel(x - y, z) < (1e-9 if dtype == torch.float64 else 2e-3)
+
+
 def _sums_of(lib, ws, j, B, H, W):
     """double[16] of pair j's workspace (csrc/scsfm_common.h: PairWs -- the B constants slots of 256 bytes come first)."""
     ws_bytes, scratch_bytes, _ = capi._sizes(lib, B, H, W)
