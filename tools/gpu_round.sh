@@ -34,6 +34,14 @@ python tools/pmc_summary.py $O/prof_$TAG --prefix pmc_iid_ --json $O/pmc_${TAG}_
 head -4 $O/pmc_$TAG.txt
 python tools/rocprof_summary.py $O/prof_$TAG/trace_results.db | grep -v "at::native\|rocclr" | head -20
 bash tools/gpu_sq.sh $TAG > $O/sq_$TAG.txt 2>&1; tail -14 $O/sq_$TAG.txt
+echo "=== the dominant kernel of this round against the previous round's on THIS box, both under rocprofv3 (variants/r0Nk.so: the current library"
+echo "    built with the old / new tuning flags -- tools/build_variants.sh r03k \"-DSCSFM_FLUSH_STEP=0 -DSCSFM_WIDE_EY=64 -DSCSFM_XCD_CHUNK=0\" r04k \"\")"
+for V in r03k r04k r03k r04k; do
+  if [ -f variants/$V.so ]; then
+    (cd /tmp; SCSFM_HIP_LIB=$R/variants/$V.so timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o ab_$V -- python $R/bench.py --loss-steps 20 --loss-warmup 5 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 3 > /dev/null 2>&1)
+    echo "$V: $(python tools/rocprof_summary.py $O/prof_$TAG/ab_${V}_results.db | grep pair_fwd_spec_kernel | head -1)" | tee -a $O/ab_kernel_$TAG.txt
+  fi
+done
 echo "=== stage timeline of the tile kernel (PROBE_TIMING build) and the column-march variant for the record"
 if [ -f variants/t4time.so ]; then SCSFM_HIP_LIB=$R/variants/t4time.so timeout 300 python tools/march_timing.py 2>&1 | tail -n 1 | tee $O/timing_${TAG}_tile.json; fi
 if [ -f variants/m3.so ]; then
