@@ -288,8 +288,21 @@ __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb
   double* __restrict__ sums = pa.sums;
   T* __restrict__ out = pa.out;
   double v[3] = {0, 0, 0};
-  for (int i = threadIdx.x; i < nblocks; i += kThreads) {
-    v[0] += partials[3 * i]; v[1] += partials[3 * i + 1]; v[2] += partials[3 * i + 2];
+  // four records per thread in flight (the loop is a chain of L2 round trips: 13 of them for the 3192 records of a
+  // configs[1] launch with one record per iteration, 4 this way); same order of additions per thread on every run
+  constexpr int U = 4;
+  for (int i0 = threadIdx.x; i0 < nblocks; i0 += U * kThreads) {
+    double q[U][3];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int i = i0 + j * kThreads;
+      const bool ok = i < nblocks;
+      const double* r = partials + 3 * (ok ? i : 0);
+      q[j][0] = r[0]; q[j][1] = r[1]; q[j][2] = r[2];
+      if (!ok) { q[j][0] = 0.0; q[j][1] = 0.0; q[j][2] = 0.0; }
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) { v[0] += q[j][0]; v[1] += q[j][1]; v[2] += q[j][2]; }
   }
   block_sum<3>(v, red);
   if (threadIdx.x == 0) {

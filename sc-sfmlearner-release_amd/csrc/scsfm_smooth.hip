@@ -163,9 +163,14 @@ __global__ __launch_bounds__(kThreads) void smooth_finalize_kernel(SmoothBatch<T
   double loss = 0.0;
   for (int b = wave; b < B; b += kThreads / kWave) {
     double v0 = 0, v1 = 0, v2 = 0;
-    for (int i = lane; i < nblk; i += kWave) {
+    // (two records per lane in flight: the 112 records of a 256 x 832 image are one round trip per image, not two)
+    for (int i = lane; i < nblk; i += 2 * kWave) {
+      const bool two = i + kWave < nblk;
       const double* q = fr.partials + 3 * ((size_t)b * nblk + i);
-      v0 += q[0]; v1 += q[1]; v2 += q[2];
+      const double* r = fr.partials + 3 * ((size_t)b * nblk + (two ? i + kWave : i));
+      const double a0 = q[0], a1 = q[1], a2 = q[2], b0 = r[0], b1 = r[1], b2 = r[2];
+      v0 += a0; v1 += a1; v2 += a2;
+      if (two) { v0 += b0; v1 += b1; v2 += b2; }
     }
     v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
     const double den = v0 / ((double)H * W) + 1e-7;  // mean_HW(D) + 1e-7, loss_functions.py:139-140

@@ -22,6 +22,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _run(cmd, env, timeout=900):
+    """bench.py in a subprocess.  One retry if the process was killed by a signal: on one box of the pool a MIOpen
+    backward solver (GemmBwdRest, requested with a null workspace at this reduced shape) took the process down with
+    'Memory access fault ... address (nil)' once in six sessions of round 4 -- inside the nets' backward, not in this
+    library; the second attempt runs the very same command."""
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    if out.returncode < 0:
+        print(f"bench.py died with signal {-out.returncode}; stderr tail: {out.stderr[-600:]}\nretrying once")
+        out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    return out
+
+
 def _last_json(out):
     lines = [l for l in out.stdout.strip().split("\n") if l.startswith("{")]
     assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-4000:]
@@ -30,8 +42,7 @@ def _last_json(out):
 
 def test_single_gpu_line_has_the_contract_fields():
     env = dict(os.environ, SCSFM_CUDNN_BENCHMARK="0", MIOPEN_FIND_MODE="FAST")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--cpu-seconds", "4"], cwd=ROOT, env=env,
-                         capture_output=True, text=True, timeout=900)
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--cpu-seconds", "4"], env)
     r = _last_json(out)
     assert r["metric"].startswith("train images/sec") and r["unit"] == "images/s" and r["n_gpus"] == 1
     assert r["steps"] == 2 and r["warmup"] == 1 and r["higher_is_better"] is True and r["vs_baseline"] is None
@@ -56,7 +67,7 @@ def test_two_ranks_sharing_the_gpu_report_a_training_rate():
     env = dict(os.environ, SCSFM_BENCH_SHARED_GPU="1", SCSFM_CUDNN_BENCHMARK="0", MIOPEN_FIND_MODE="FAST")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--cpu-seconds", "0"]
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = _run(cmd, env)
     r = _last_json(out)
     # (gloo between the two ranks that share the GPU: the line says so and does not call them RCCL ranks)
     assert r["n_gpus"] == 2 and r["collective_backend"] == "gloo" and r["collective_ranks"] == 2 and "rccl_ranks" not in r
@@ -72,8 +83,8 @@ def test_one_rank_over_rccl(exact):
     gradient_as_bucket_view), training steps in the default and in the exact mask-normalisation mode (all-reduce of the
     pairs' raw sums on a HIP tensor + re-finalisation), the hot path eager and as a HIP-graph replay (--graph 2)."""
     env = dict(os.environ, SCSFM_CUDNN_BENCHMARK="0", MIOPEN_FIND_MODE="FAST", MASTER_PORT=str(_free_port()))
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--cpu-seconds", "0", "--force-dist", "nccl",
-                          "--exact", str(exact), "--graph", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--cpu-seconds", "0", "--force-dist", "nccl",
+                "--exact", str(exact), "--graph", "2"], env)
     r = _last_json(out)
     assert r["collective_backend"] == "nccl" and r["rccl_ranks"] == 1 and r["n_gpus"] == 1
     assert r["exact_mask_normalisation"] == bool(exact)

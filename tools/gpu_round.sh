@@ -34,6 +34,9 @@ python tools/pmc_summary.py $O/prof_$TAG --prefix pmc_iid_ --json $O/pmc_${TAG}_
 head -4 $O/pmc_$TAG.txt
 python tools/rocprof_summary.py $O/prof_$TAG/trace_results.db | grep -v "at::native\|rocclr" | head -20
 bash tools/gpu_sq.sh $TAG > $O/sq_$TAG.txt 2>&1; tail -14 $O/sq_$TAG.txt
+echo "=== library launches per single-node step (20 eager steps of compute_total_loss + backward under rocprofv3)"
+(cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o sn -- python $R/tools/step_launches.py --steps 20 > /dev/null 2>&1)
+python tools/rocprof_summary.py $O/prof_$TAG/sn_results.db | grep "scsfm::" | head -14 | tee $O/single_node_launches_$TAG.txt
 echo "=== the dominant kernel of this round against the previous round's on THIS box, both under rocprofv3 (variants/r0Nk.so: the current library"
 echo "    built with the old / new tuning flags -- tools/build_variants.sh r03k \"-DSCSFM_FLUSH_STEP=0 -DSCSFM_WIDE_EY=64 -DSCSFM_XCD_CHUNK=0\" r04k \"\")"
 for V in r03k r04k r03k r04k; do
