@@ -159,7 +159,9 @@ class StepLoss(torch.autograd.Function):
     Compared with the reference's two functions plus the weighted sum this saves what autograd does between
     them: five scalar kernels forward, three backward, and one elementwise addition per depth map (the smooth
     gradient is accumulated into the buffers the pair backward just stored).  The speculation hint is the
-    weights themselves, so it always holds when the upstream gradient of the loss is 1."""
+    weights themselves -- this node knows them, unlike PhotoGeometryLoss, which learns the ratio from the upstream
+    gradients it sees and therefore keeps it on the device (config.hint_tensor) -- so the speculation holds whatever
+    the upstream gradient of the loss is (the check is on the RATIO of the two terms' gradients)."""
 
     @staticmethod
     def forward(ctx, flags, n_ref, n_scales, w_photo, w_smooth, w_geom, tgt_img, K, *rest):
