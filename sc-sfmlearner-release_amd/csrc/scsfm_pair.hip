@@ -347,7 +347,7 @@ __global__ void pair_refinalize_kernel(double* __restrict__ sums, T* __restrict_
 // when the speculative forward's results do not stand (spec_valid) or no speculative forward ran.
 // ==========================================================================================
 //
-// The SPECULATIVE FORWARD (scsfm_march.h) runs the forward with unit photo coefficient and the geometry / photo
+// The SPECULATIVE FORWARD (scsfm_spec_tile.h) runs the forward with unit photo coefficient and the geometry / photo
 // coefficient ratio r = 3 w_geom / w_photo the caller expects the upstream gradients to have (the loss weights are
 // constants of a training run, train.py:268).  It produces the three sums of the forward AND carries on through
 // both passes of the backward for the pixels it owns: the pair's dense / scatter planes and pose partials, all up
@@ -401,14 +401,14 @@ constexpr unsigned kRuntimeFlags = 0xffffffffu;
 constexpr unsigned kTrainFlags = SCSFM_WITH_SSIM | SCSFM_WITH_MASK | SCSFM_WITH_AUTO_MASK;  // zeros padding
 }  // namespace scsfm
 #include "scsfm_spec_tile.h"  // the speculative forward proper (needs PairArgs / PairBatch / the plane indices above)
-#ifdef SCSFM_WITH_MARCH       // tuning / test builds only (tools/build_variants.sh, tests/hostsim): the column-march
-#include "scsfm_march.h"      // variant of the speculative forward, selected at run time with SCSFM_SPEC_KERNEL=march
+#ifdef SCSFM_WITH_MARCH       // tuning / test builds only (tools/build_variants.sh, tests/hostsim; -Ivariants/src): the column-march
+#include "scsfm_march.h"      // variant of the speculative forward (variants/src/), selected at run time with SCSFM_SPEC_KERNEL=march
 #endif
 namespace scsfm {
 
 // The speculative forward: one tile per workgroup, XCD-aware order.
 // (kStageFwd: the forward warp's taps staged in LDS as well -- scsfm_spec_tile.h; tuning / test builds instantiate both)
-template <typename T, bool kSsim, unsigned kFlags = kRuntimeFlags, bool kScaled = false, bool kStageFwd = (SCSFM_STAGE_FWD != 0)>
+template <typename T, bool kSsim, unsigned kFlags = kRuntimeFlags, bool kScaled = false, bool kStageFwd = false>
 __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) void pair_fwd_spec_kernel(PairBatch<T> pb, int B, int H, int W,
                                                                                   unsigned flags, T r_hint,
                                                                                   const double* __restrict__ hint) {
@@ -1161,7 +1161,7 @@ static bool spec_stages_fwd() {
 #endif
 }
 #ifdef SCSFM_WITH_MARCH
-// Rows of a segment of the speculative forward's column march (scsfm_march.h).  A segment costs 4 extra warped rows
+// Rows of a segment of the speculative forward's column march (variants/src/scsfm_march.h).  A segment costs 4 extra warped rows
 // and a last, mostly idle chunk, so segments should be long; the launch should still be many times the 1024
 // workgroups the chip holds (4 per CU), so they cannot be too long.  SCSFM_MARCH_ROWS overrides (tests, tuning).
 static int march_seg_rows(int H, int chunk, int units) {

@@ -1,6 +1,6 @@
 // The speculative forward of a pair-direction as one 64 x 16 tile per workgroup (the product of rounds 1 and 2): warp in a
 // 66 x 18 domain, forward statistics at every pixel of the 64 x 16 domain, transposed box filter and geometry tail for
-// the 62 x 14 interior.  Four workgroups per CU (128 VGPRs, 40 KB of LDS: kLean).  The column march of scsfm_march.h
+// the 62 x 14 interior.  Four workgroups per CU (128 VGPRs, 40 KB of LDS: kLean).  The column march of variants/src/scsfm_march.h
 // issues 15-20 % fewer vector instructions per output pixel but was measured slower on MI355X: what bounds
 // both kernels is the chain of dependent memory / LDS round trips and barriers of a workgroup, and short-lived tiles at
 // four per CU overlap those chains better than long-lived segments at two or three.
@@ -9,6 +9,9 @@
 #pragma once
 #include "scsfm_geom.h"
 #include "scsfm_ssim.h"
+#ifdef SCSFM_WITH_MARCH  // tuning / test builds (-Ivariants/src): the staged-forward variant's tap reader
+#include "scsfm_stagefwd_taps.h"
+#endif
 
 namespace scsfm {
 
@@ -26,11 +29,8 @@ __device__ __forceinline__ void sched_fence() {
 #ifndef SCSFM_STAGE_TAPS  // tuning knob: 0 = the tail gathers its taps from global memory
 #define SCSFM_STAGE_TAPS 1
 #endif
-#ifndef SCSFM_STAGE_FWD  // tuning knob: 1 = the forward warp reads its taps from an LDS-staged window too (measured 2.4 %
-#define SCSFM_STAGE_FWD 0  // slower; tuning / test builds carry both and select with SCSFM_SPEC_KERNEL=stagefwd)
-#endif
 
-template <typename T, bool kSsim, bool kScaled, unsigned kFlags, bool kStageFwd = (SCSFM_STAGE_FWD != 0)>
+template <typename T, bool kSsim, bool kScaled, unsigned kFlags, bool kStageFwd = false>
 // (kSpec: always true here -- the backward's own tiled pass is photo_tile in scsfm_pair.hip)
 __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, const PairBatch<T>& pb, int B, int H,
                                            int W, unsigned flags_arg, const T* __restrict__ g_photo,
@@ -113,167 +113,13 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
 #endif
   STAMP(0);
   T in_d[STRIP];
-  // SCSFM_STAGE_FWD (fp32 + SSIM): the forward warp reads its 2 x 2 blocks from LDS.  The pixels are projected first
-  // (their depths are the only loads in front), the bounding box of where they land places a 72 x 20 window of the
-  // reference view -- colours and depth -- which the workgroup fetches with coalesced row loads into LDS regions that
-  // are idle during the warp (two planes in sG, one each in the tiles of colours 2 and 1), and every pixel's four
-  // planes are then 8 two-dword LDS reads instead of 8 per-lane gathers (blocks outside the window: gathers, as
-  // before).  The warped colours of the two tiles that hold staged planes wait in registers for one barrier.
+#ifdef SCSFM_WITH_MARCH  // tuning / test builds only: the forward warp with LDS-staged taps (variants/src/; measured slower)
   constexpr bool kStageF = kStageFwd && kSpec && kSsim && sizeof(T) == 4 && TH == kTileH;
   if constexpr (kStageF) {
-    constexpr int FW = kFwdStageW, FH = kFwdStageH, NP = STRIP + 1, NW = kThreads / kWave, XC = FW - kWave, NI = FH / NW;
-    static_assert(FH % NW == 0 && XC * FH <= kThreads && XC > 0, "staging loop shape");
-    static_assert(3 * TH * kTileW >= 2 * FW * FH && int(sizeof(V2) / sizeof(T)) * (TH + 2) * kHaloW >= FW * FH, "staging space");
-    T* const l0 = &sG[0][0][0];
-    T* const l1 = l0 + FW * FH;
-    T* const l2 = reinterpret_cast<T*>(&sXY[2][0][0]);
-    T* const ld = reinterpret_cast<T*>(&sXY[1][0][0]);
-    const int u = reflect_index(px, W);
-    const bool has_ring = threadIdx.x < 2 * kHaloW + 2 * TH;
-    int ru = 0, rv = 0, rhy = 0, rhx = 0;
-    // ---- (1) depths, projection, bounding box of the landing positions ---------------------------
-    T rin_d = T(1);
-#pragma unroll
-    for (int k = 0; k < STRIP; ++k) {
-      const int v = reflect_index(py0 + k, H);
-      in_d[k] = tgt_depth.at(u, v, (unsigned(v) * unsigned(W) + unsigned(u)) * unsigned(sizeof(T)));
-    }
-    if (has_ring) {
-      ring_pos<TH>(threadIdx.x, rhy, rhx);
-      ru = reflect_index(ox + rhx - 1, W); rv = reflect_index(oy + rhy - 1, H);
-      rin_d = tgt_depth.at(ru, rv, (unsigned(rv) * unsigned(W) + unsigned(ru)) * unsigned(sizeof(T)));
-    }
-    Sample<T> sm[NP];
-    int fx0 = 1 << 30, fx1 = -(1 << 30), fy0 = 1 << 30, fy1 = -(1 << 30);
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      sm[j] = j < STRIP ? project_pixel(bc, u, reflect_index(py0 + j, H), in_d[j], H, W, flags)
-                        : project_pixel(bc, ru, rv, rin_d, H, W, flags);
-      // (a sample without any weight -- the zeros-mode overwrite, a position outside the image -- reads nothing)
-      // (with the zeros-mode overwrite that is exactly the valid flag)
-      const bool overwrite = (flags & (SCSFM_PAD_BORDER | SCSFM_LEGACY_GRID)) == 0;
-      const bool weighs = overwrite ? sm[j].valid : (sm[j].wp[0] + sm[j].wp[1]) + (sm[j].wp[2] + sm[j].wp[3]) != T(0);
-      const bool live = (j < STRIP || has_ring) && weighs;
-      const int xlo = live ? sm[j].xa : 1 << 30, xhi = live ? sm[j].xa : -(1 << 30);
-      const int ylo = live ? sm[j].ya : 1 << 30, yhi = live ? sm[j].ya : -(1 << 30);
-      fx0 = xlo < fx0 ? xlo : fx0; fx1 = xhi > fx1 ? xhi : fx1;
-      fy0 = ylo < fy0 ? ylo : fy0; fy1 = yhi > fy1 ? yhi : fy1;
-    }
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) {
-      const int a0 = __shfl_xor(fx0, o), a1 = __shfl_xor(fx1, o), c0 = __shfl_xor(fy0, o), c1 = __shfl_xor(fy1, o);
-      fx0 = a0 < fx0 ? a0 : fx0; fx1 = a1 > fx1 ? a1 : fx1; fy0 = c0 < fy0 ? c0 : fy0; fy1 = c1 > fy1 ? c1 : fy1;
-    }
-    if (col == 0) { sBox[strip][0] = fx0; sBox[strip][1] = fx1; sBox[strip][2] = fy0; sBox[strip][3] = fy1; }
-    __syncthreads();
-    {
-      int x0 = sBox[0][0], x1 = sBox[0][1], y0 = sBox[0][2], y1 = sBox[0][3];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) {
-        x0 = sBox[w][0] < x0 ? sBox[w][0] : x0; x1 = sBox[w][1] > x1 ? sBox[w][1] : x1;
-        y0 = sBox[w][2] < y0 ? sBox[w][2] : y0; y1 = sBox[w][3] > y1 ? sBox[w][3] : y1;
-      }
-      const int ex = x1 - x0 + 2, ey = y1 - y0 + 2;  // texels touched (each block reaches one past its first)
-      fx0 = ex <= FW ? x0 - (FW - ex) / 2 : (x0 + x1 + 1) / 2 - FW / 2;
-      fy0 = ey <= FH ? y0 - (FH - ey) / 2 : (y0 + y1 + 1) / 2 - FH / 2;
-      fx0 = fx0 > W - FW ? W - FW : fx0; fx0 = fx0 < 0 ? 0 : fx0;
-      fy0 = fy0 > H - FH ? H - FH : fy0; fy0 = fy0 < 0 ? 0 : fy0;
-      // incoherent depth (the landing positions spread over far more than a window): nothing is staged
-      fx1 = (x0 <= x1 && ex <= 2 * FW && ey <= 2 * FH) ? 1 : 0;
-    }
-    fx0 = __builtin_amdgcn_readfirstlane(fx0); fy0 = __builtin_amdgcn_readfirstlane(fy0);
-    const bool staged = __builtin_amdgcn_readfirstlane(fx1) != 0;  // uniform over the workgroup
-    // ---- (2) the window: coalesced rows -> LDS ----------------------------------------------------
-    if (staged) {
-      T sv[4][NI + 1];
-      const int gx = fx0 + col < W ? fx0 + col : W - 1;
-      const int er = int(threadIdx.x) / XC, ec = kWave + int(threadIdx.x) - er * XC;
-      const int egx = fx0 + ec < W ? fx0 + ec : W - 1, egy = fy0 + er < H ? fy0 + er : H - 1;
-      const bool extra = threadIdx.x < XC * FH;
-#pragma unroll
-      for (int i = 0; i <= NI; ++i) {
-        const int r = strip + i * NW;
-        const int gy = fy0 + r < H ? fy0 + r : H - 1;
-        const int x = i < NI ? gx : egx, y = i < NI ? gy : egy;
-        const unsigned off = (unsigned(y) * unsigned(W) + unsigned(x)) * unsigned(sizeof(T));
-#pragma unroll
-        for (int c = 0; c < 4; ++c) sv[c][i] = T(0);
-        if (i < NI || extra) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) sv[c][i] = ld_at(ref_img + c * plane, off);
-          sv[3][i] = ref_depth.at(x, y, off);
-        }
-      }
-      T* const lp[4] = {l0, l1, l2, ld};
-#pragma unroll
-      for (int i = 0; i <= NI; ++i) {
-        const int o = i < NI ? (int(threadIdx.x) / kWave + i * NW) * FW + col : er * FW + ec;
-        if (i < NI || extra) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) lp[c][o] = sv[c][i];
-        }
-      }
-    }
-    // ---- (3) target colours (and the un-warped reference colours of the auto-mask) ------------------
-    T in_t[NP][3], in_r[STRIP][3];
-#pragma unroll
-    for (int k = 0; k < STRIP; ++k) {
-      const unsigned off = (unsigned(reflect_index(py0 + k, H)) * unsigned(W) + unsigned(u)) * unsigned(sizeof(T));
-#pragma unroll
-      for (int c = 0; c < 3; ++c) in_t[k][c] = ld_at(tgt_img + c * plane, off);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) in_r[k][c] = T(0);
-      if (with_auto) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) in_r[k][c] = ld_at(ref_img + c * plane, off);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) in_t[STRIP][c] = T(0);
-    if (has_ring) {
-      const unsigned off = (unsigned(rv) * unsigned(W) + unsigned(ru)) * unsigned(sizeof(T));
-#pragma unroll
-      for (int c = 0; c < 3; ++c) in_t[STRIP][c] = ld_at(tgt_img + c * plane, off);
-    }
-    sched_fence();
-    __syncthreads();
-    // ---- (4) every pixel's blocks ------------------------------------------------------------------
-    V2 hold[NP][2];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      hold[j][0] = make2(T(0), T(0)); hold[j][1] = hold[j][0];
-      if (j == STRIP && !has_ring) continue;
-      const Sample<T>& s = sm[j];
-      TapRows<T> tc[3], td;
-      if (j < STRIP) fwd_taps<true>(s, staged, fx0, fy0, l0, l1, l2, ld, ref_img, plane, ref_depth, tc, td);
-      else fwd_taps<false>(s, staged, fx0, fy0, l0, l1, l2, ld, ref_img, plane, ref_depth, tc, td);
-      V2 xy[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) xy[c] = make2(in_t[j][c], bilerp_rows(tc[c], s));
-      hold[j][0] = xy[1]; hold[j][1] = xy[2];
-      if (j == STRIP) { sXY[0][rhy][rhx] = xy[0]; continue; }
-      const int k = j;
-      sXY[0][lrow + k + 1][col + 1] = xy[0];
-      const int ly = strip * STRIP + k, py = py0 + k;
-      const bool inimg = px >= 0 && px < W && py >= 0 && py < H;
-      const T Dp = bilerp_rows(td, s);
-      const T ddk = clamp01(t_abs(s.Z - Dp) * t_rcp(s.Z + Dp));
-      mq[k] = inimg ? pixel_mask(s, with_auto, xy, in_r[k]) : T(0);
-      coef[k] = a * mq[k] * (with_mask ? (T(1) - ddk) : T(1));
-      bsum[k] = T(0);
-      if (in_x && ly >= 1 && ly <= TH - 2 && py < H) { acc_g += ddk * mq[k]; acc_m += mq[k]; }
-    }
-    // (the scatter window of the tail is placed on the same boxes: the landing positions of every pixel of the domain
-    // that reads anything, a pixel or two wider than those of the owned pixels that will scatter)
-    STAMP(1);
-    __syncthreads();  // the staged planes in the tiles of colours 1 and 2 are dead
-#pragma unroll
-    for (int k = 0; k < STRIP; ++k) { sXY[1][lrow + k + 1][col + 1] = hold[k][0]; sXY[2][lrow + k + 1][col + 1] = hold[k][1]; }
-    if (has_ring) { sXY[1][rhy][rhx] = hold[STRIP][0]; sXY[2][rhy][rhx] = hold[STRIP][1]; }
-    STAMP(2);
-    __syncthreads();
-    STAMP(3);
-  } else {
+#include "scsfm_spec_stagefwd.inc"
+  } else
+#endif
+  {
     // ---- phase 0: every streaming load of the strip and of this thread's ring pixel ---------------
     const int u = reflect_index(px, W);
     T in_t[STRIP][3], in_r[STRIP][3], rin_d = T(0), rin_t[3] = {T(0), T(0), T(0)};

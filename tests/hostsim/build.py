@@ -11,6 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "sc-sfmlearner-release_amd", "csrc")
+VSRC = os.path.join(ROOT, "variants", "src")  # experimental kernels that are not product sources (column march, staged forward warp)
 # HOSTSIM_EXTRA="-DSCSFM_X=1 ...": a tuning variant of the kernels under the same tests (its objects go to their own
 # directory, so that the default build is not disturbed)
 EXTRA = os.environ.get("HOSTSIM_EXTRA", "").split()
@@ -20,7 +21,7 @@ LIB = os.path.join(OUT, "libscsfm_hostsim.so")
 
 def build(force=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "hip", "hip_runtime.h"),
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(VSRC, "*")) + [os.path.join(HERE, "hip", "hip_runtime.h"),
                                                            os.path.join(ROOT, "include", "scsfm_hip.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
@@ -32,7 +33,7 @@ def build(force=False):
         objs.append(o)
         procs.append(subprocess.Popen(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "c++", "-I", HERE,
                                        "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
-                                       "-DSCSFM_WITH_MARCH",  # the experimental column-march variant stays testable here
+                                       "-DSCSFM_WITH_MARCH", "-I", VSRC, "-I", CSRC,  # the experimental variants (variants/src/) stay testable here
                                        *EXTRA,
                                        "-c", s, "-o", o]))
     for p in procs:
