@@ -288,6 +288,30 @@ def library_identity(lib):
             "env_override": bool(os.environ.get("SCSFM_HIP_LIB"))}
 
 
+def torchrun_command(n_gpus, argv, port=None):
+    """The command `python bench.py --gpus N ...` turns itself into when it was started without a launcher: one rank per
+    GPU of ONE node over 127.0.0.1 (the container's hostname may not resolve), the same arguments."""
+    if port is None:
+        import socket
+        with socket.socket() as sock:  # a free port: two benches on one box must not meet on a fixed one
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(n_gpus, argv):
+    """Re-execute under torch.distributed.run; the ranks inherit stdout (rank 0 prints the one JSON line) and stderr;
+    the launcher's exit status -- non-zero if any rank failed -- becomes ours."""
+    import subprocess
+    cmd = torchrun_command(n_gpus, argv)
+    log("bench.py: --gpus %d without a launcher: re-executing as `%s`" % (n_gpus, " ".join(cmd)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,8 +351,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # started as plain `python bench.py --gpus N` (the form the driver's N = 1 command has): become the launcher
+            sys.exit(self_launch(args.gpus, sys.argv[1:]))
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the loss path has no CPU fallback")

@@ -22,14 +22,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
+MIOPEN_CRASH = ("GemmBwdRest", "MIOpen", "miopen")  # what the one crash this retry exists for leaves on stderr
+
+
 def _run(cmd, env, timeout=900):
-    """bench.py in a subprocess.  One retry if the process was killed by a signal: on one box of the pool a MIOpen
-    backward solver (GemmBwdRest, requested with a null workspace at this reduced shape) took the process down with
-    'Memory access fault ... address (nil)' once in six sessions of round 4 -- inside the nets' backward, not in this
-    library; the second attempt runs the very same command."""
+    """bench.py in a subprocess.  One retry ONLY for the known crash: on one box of the pool a MIOpen backward solver
+    (GemmBwdRest, requested with a null workspace at this reduced shape) took the process down with 'Memory access
+    fault ... address (nil)' once in six sessions of round 4 -- inside the nets' backward, not in this library.  A
+    process killed by a signal WITHOUT that signature on stderr (e.g. a fault of this library's own kernels) is not
+    retried: the caller's assertion on the return code fails with its stderr."""
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    if out.returncode < 0:
-        print(f"bench.py died with signal {-out.returncode}; stderr tail: {out.stderr[-600:]}\nretrying once")
+    if out.returncode < 0 and any(k in out.stderr for k in MIOPEN_CRASH) and "address (nil)" in out.stderr:
+        import warnings
+        warnings.warn(f"bench.py died with signal {-out.returncode} inside MIOpen (known, null-workspace solver); "
+                      f"retrying once.  stderr tail: {out.stderr[-400:]}")
         out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     return out
 
@@ -91,3 +97,17 @@ def test_one_rank_over_rccl(exact):
     assert r["value"] > 0 and r["train"]["final_loss"] == r["train"]["final_loss"]
     assert "ddp1" in r["config"]["parallelism"]
     assert r["warp_loss"]["graph_error"] is None
+
+
+def test_gpus_2_without_a_launcher_launches_itself():
+    """`python bench.py --gpus 2` started WITHOUT torch.distributed.run -- the form the driver's N = 1 command has -- must
+    not die on launch: it re-executes itself under the launcher (127.0.0.1, a free port), rank 0 prints the one JSON
+    line and the ranks' exit status comes back.  Two ranks on the box's one GPU (gloo), as above."""
+    env = dict(os.environ, SCSFM_BENCH_SHARED_GPU="1", SCSFM_CUDNN_BENCHMARK="0", MIOPEN_FIND_MODE="FAST")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--e2e", "1", *SMALL, "--cpu-seconds", "0"], env)
+    r = _last_json(out)
+    assert r["n_gpus"] == 2 and r["collective_ranks"] == 2 and r["config"]["global_batch"] == 4
+    assert r["steps"] == 2 and r["value"] > 0 and "ddp2" in r["config"]["parallelism"]
+    assert "re-executing as" in out.stderr
