@@ -57,7 +57,7 @@ def step_bytes(n_px, n_ref):
 def make_inputs(args, seed, device):
     from scsfm_hip import synth
     d = synth.make_batch(args.batch, args.height, args.width, n_ref=args.n_ref, seed=seed, depth=args.depth,
-                         image="smooth" if args.depth == "smooth" else "iid", dataset=args.dataset)
+                         image=synth.image_law(args.depth), dataset=args.dataset)
     to = lambda t: t.to(device)
     return {
         "tgt_img": to(d["tgt_img"]), "ref_imgs": [to(t) for t in d["ref_imgs"]], "K": to(d["intrinsics"]),
@@ -323,9 +323,10 @@ def main():
     ap.add_argument("--n-ref", type=int, default=2, help="sequence length - 1")
     ap.add_argument("--dataset", default="kitti", choices=["kitti", "nyu"])
     ap.add_argument("--resnet-layers", type=int, default=18, choices=[18, 50], help="DispResNet encoder (configs[3]: 50)")
-    ap.add_argument("--depth", default="smooth", choices=["smooth", "iid"],
+    ap.add_argument("--depth", default="smooth", choices=["smooth", "iid", "scene"],
                     help="synthetic depth law of the hot-path legs: smooth = realistic locality (headline), iid = "
-                         "incoherent gathers")
+                         "incoherent gathers, scene = piecewise-smooth depth with occlusion edges on ~5 %% of the pixels "
+                         "(what a trained DispResNet emits; scsfm_hip.synth)")
     ap.add_argument("--loss-steps", type=int, default=50, help="timed steps of the hot-path (loss only) legs")
     ap.add_argument("--loss-warmup", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline (0 = skip)")

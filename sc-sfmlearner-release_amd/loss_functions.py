@@ -109,6 +109,10 @@ def compute_smooth_loss(tgt_depth, tgt_img, ref_depths, ref_imgs):
     return ops.SmoothLoss.apply(len(depths), *depths, *imgs)
 
 
+# frames one launch of scsfm_smooth_multi_fwd_step holds (csrc/scsfm_smooth.hip: kMaxFrames)
+MAX_FUSED_FRAMES = 8
+
+
 def compute_total_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, poses, poses_inv, max_scales, with_ssim,
                        with_mask, with_auto_mask, padding_mode, w_photo, w_smooth, w_geom):
     """Not in the reference: what train.py:259-268 computes -- compute_photo_and_geometry_loss,
@@ -123,6 +127,14 @@ def compute_total_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, pos
     b, _, h, w = tgt_img.size()
     flags = capi.make_flags(with_ssim, with_mask, with_auto_mask, padding_mode)
 
+    if 1 + n_ref > MAX_FUSED_FRAMES:
+        # the fused smooth forward / combine hold one launch's frames (8 = target + 7 references; the combine caps at
+        # 16): longer sequences take the reference's call structure -- same values and gradients, three autograd nodes
+        photo, geom = compute_photo_and_geometry_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, poses, poses_inv,
+                                                      max_scales, with_ssim, with_mask, with_auto_mask, padding_mode)
+        smooth = compute_smooth_loss(tgt_depth, tgt_img, ref_depths, ref_imgs)
+        loss = w_photo * photo + w_smooth * smooth + w_geom * geom
+        return loss, photo.detach(), smooth.detach(), geom.detach()
     tgt_full, ref_full = _scale_maps(tgt_depth, ref_depths, n_ref, num_scales, b, h, w)
     return ops.StepLoss.apply(flags, n_ref, num_scales, float(w_photo), float(w_smooth), float(w_geom), tgt_img, intrinsics,
                               *ref_imgs, *tgt_full, *ref_full, *poses[:n_ref], *poses_inv[:n_ref])

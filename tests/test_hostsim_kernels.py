@@ -413,6 +413,33 @@ def test_four_scales_read_in_place_fp64(lib, hint, upstream, pad):
         assert _rel(g_p[i], pp[i].grad) < 1e-10 and _rel(g_pi[i], pi[i].grad) < 1e-10
 
 
+@pytest.mark.parametrize("hint,upstream", [((1.0, 0.5), (1.0, 0.5)), (None, (1.0, 0.5))])
+def test_scene_depth_law_fp64(lib, hint, upstream):
+    """The `scene` law of round 5 (piecewise-smooth depth, occlusion edges with disparity jumps of tens of pixels,
+    image edges on the depth's): the taps of one tile land in two separate places of the reference view, so the
+    scatter window / staged taps / direct atomics all carry part of a tile.  fp64 kernels against the oracle."""
+    B, H, W = 2, 96, 160
+    d = synth.make_batch(B, H, W, n_ref=1, seed=71, depth="scene", image="scene", pose_scale=0.02)
+    assert synth.scene_edge_fraction(d["tgt_depth"][0]) > 0.02
+    c = lambda x: x.double().contiguous()
+    ti, K = c(d["tgt_img"]), c(d["intrinsics"])
+    ris = [c(r) for r in d["ref_imgs"]]
+    tds, rds = [c(t) for t in d["tgt_depth"]], [[c(t) for t in r] for r in d["ref_depths"]]
+    ps, pis = [c(p) for p in d["poses"]], [c(p) for p in d["poses_inv"]]
+    td, rd = [leaf(t) for t in tds], [[leaf(t) for t in r] for r in rds]
+    pp, pi = [leaf(p) for p in ps], [leaf(p) for p in pis]
+    photo_o, geom_o = O.photo_and_geometry_loss(ti, ris, K, td, rd, pp, pi, 1, 1, 1, 1, "zeros")
+    (upstream[0] * photo_o + upstream[1] * geom_o).backward()
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    photo, geom, outs, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=hint)
+    assert abs(float(photo) - float(photo_o)) < 1e-11 and abs(float(geom) - float(geom_o)) < 1e-11
+    g_td, g_rd, g_p, g_pi = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws,
+                                                    torch.tensor([upstream[0]], dtype=torch.float64),
+                                                    torch.tensor([upstream[1]], dtype=torch.float64))
+    assert _rel(g_td[0], td[0].grad) < 1e-10 and _rel(g_rd[0][0], rd[0][0].grad) < 1e-10
+    assert _rel(g_p[0], pp[0].grad) < 1e-10 and _rel(g_pi[0], pi[0].grad) < 1e-10
+
+
 def test_large_gradients_bypass_the_fixed_point_window(lib):
     """The fp32 speculative forward stages dL/dD_ref in 32-bit fixed-point LDS cells (range +-2048).  Depths just
     above cam2pixel2's 1e-3 clamp and a geometry weight of 5 make the unscaled per-pixel term r * 2Z / (Z + D_p)^2
@@ -584,6 +611,39 @@ def test_single_node_step_equals_the_three_reference_style_calls(lib, monkeypatc
     assert abs(float(loss) - float(w1 * photo + w2 * smooth + w3 * geom)) < 1e-13
     for a, b in zip(td + [t for r in rd for t in r] + pp + pi, td2 + [t for r in rd2 for t in r] + pp2 + pi2):
         assert _rel(b.grad, a.grad) < 1e-11
+
+
+def test_single_node_step_with_more_frames_than_one_fused_launch(lib, monkeypatch):
+    """Target + 8 references = 9 frames > the 8 one launch of scsfm_smooth_multi_fwd_step holds (and 16 pair-directions
+    = two launches per pair stage): compute_total_loss falls back to the reference's call structure instead of raising
+    (round-4 advisor finding); values and gradients against the oracle, fp64."""
+    import loss_functions as LF
+    from scsfm_hip import _lib, ops
+    monkeypatch.setattr(_lib, "get", lambda: lib)
+    monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)
+    n_ref = 8
+    assert 1 + n_ref > LF.MAX_FUSED_FRAMES
+    d = synth.make_batch(4, 48, 80, n_ref=n_ref, seed=43, depth="smooth")  # (enough pixels to open the 10000-pixel gates)
+    c = lambda x: x.double().contiguous()
+    ti, K, ris = c(d["tgt_img"]), c(d["intrinsics"]), [c(r) for r in d["ref_imgs"]]
+    w1, w2, w3 = 1.0, 0.1, 0.5
+
+    def leaves():
+        return ([leaf(c(t)) for t in d["tgt_depth"]], [[leaf(c(t)) for t in r] for r in d["ref_depths"]],
+                [leaf(c(p)) for p in d["poses"]], [leaf(c(p)) for p in d["poses_inv"]])
+
+    td, rd, pp, pi = leaves()
+    photo, geom = O.photo_and_geometry_loss(ti, ris, K, td, rd, pp, pi, 1, 1, 1, 1, "zeros")
+    smooth = O.smooth_loss(td, ti, rd, ris)
+    (w1 * photo + w2 * smooth + w3 * geom).backward()
+    td2, rd2, pp2, pi2 = leaves()
+    loss, l1, l2, l3 = LF.compute_total_loss(ti, ris, K, td2, rd2, pp2, pi2, 1, 1, 1, 1, "zeros", w1, w2, w3)
+    assert not l1.requires_grad and not l2.requires_grad and not l3.requires_grad
+    loss.backward()
+    assert abs(float(l1) - float(photo)) < 1e-11 and abs(float(l2) - float(smooth)) < 1e-11 and abs(float(l3) - float(geom)) < 1e-11
+    assert float(photo) > 0 and float(geom) > 0
+    for a, b in zip(td + [t for r in rd for t in r] + pp + pi, td2 + [t for r in rd2 for t in r] + pp2 + pi2):
+        assert _rel(b.grad, a.grad) < 1e-10
 
 
 @pytest.mark.parametrize("H,W,dtype,hint,upstream", [
