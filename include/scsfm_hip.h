@@ -64,8 +64,9 @@ extern "C" {
  * scsfm_source_id.  8: scsfm_pairs_bwd_smooth, scsfm_smooth_multi_fwd_step.  7: gradients of the data inputs -- scsfm_pair_desc::g_tgt_img / g_ref_img, scsfm_pairs_bwd_inputs,
  * scsfm_warp_bwd_inputs, scsfm_pixel2cam_bwd_intrinsics, scsfm_masked_mean_bwd_mask, scsfm_smooth_multi_bwd_images). */
 int scsfm_abi_version(void);
-/* Identity of the sources this binary was built from: the first 16 hex digits of the sha256 over csrc/ and this header
- * (scsfm_hip/build.py: source_id(); "unknown" for a build that did not record it), NUL-terminated into buf[n]. */
+/* Identity of what this binary was built from: the first 16 hex digits of the sha256 over csrc/, this header AND the
+ * compiler flags, any extra -D tuning knobs included (scsfm_hip/build.py: source_id(extra); "unknown" for a build that
+ * did not record it), NUL-terminated into buf[n].  A tuning variant therefore never carries the default library's id. */
 int scsfm_source_id(char* buf, size_t n);
 
 /* ---------------------------------------------------------------------------------------------
@@ -407,7 +408,8 @@ int scsfm_step_weights_f64(const double* g_loss, double w_photo, double w_smooth
  * produces: custom_transforms.py:62-84) with monotone first indices and at most 5 taps -- a 64 x 16 tile of outputs then
  * reads at most 69 x 21 source pixels, which is what the kernel stages in LDS.  Tables outside that class are not
  * rejected (they live on the device); the kernel clamps every index they imply into its staging arrays, so such a call
- * returns meaningless pixels but never touches memory it does not own.
+ * returns meaningless pixels but never touches memory outside [frames, frames + n_frames * H * W * 3) (the window's
+ * first row / column are clamped into the frame and the dword loads are guarded at both ends of the buffer).
  * --------------------------------------------------------------------------------------------- */
 int scsfm_augment_u8_f32(int n_frames, int frames_per_sample, int H, int W, const unsigned char* frames,
                          const int* params, const int* htab, const int* vtab, const float* lut, float* out,

@@ -40,6 +40,15 @@ constexpr int kAugSrcRows = kAugRows + 5;     // source rows a tile can touch (z
 constexpr int kAugSrcCols = kWave + 5;        // ... and source columns
 constexpr int kAugRowBytes = ((kAugSrcCols * 3 + 3 + 3) / 4) * 4;  // window row in LDS (+ up to 3 bytes of alignment slack)
 
+// First byte of a tile's source window in frame row `row`, column `col`.  Under the precondition both lie inside the
+// frame; tables outside the documented class (a negative first row, h1 > W under a flip) are clamped into it, so that
+// no address below `frames` or beyond the buffer is ever formed (round-4 advisor finding: only the upper end was guarded).
+__device__ __forceinline__ const uint8_t* aug_row_first(const uint8_t* __restrict__ src, int row, int col, int H, int W) {
+  row = row < 0 ? 0 : (row > H - 1 ? H - 1 : row);
+  col = col < 0 ? 0 : (col > W - 1 ? W - 1 : col);
+  return src + ((size_t)row * W + col) * 3;
+}
+
 __global__ __launch_bounds__(kThreads) void augment_kernel(int T, int H, int W, const uint8_t* __restrict__ frames,
                                                            const int* __restrict__ params,
                                                            const int* __restrict__ htab, const int* __restrict__ vtab,
@@ -60,8 +69,9 @@ __global__ __launch_bounds__(kThreads) void augment_kernel(int T, int H, int W, 
   // in frame coordinates a flipped tile reads columns W - h1 .. W - 1 - h0
   // PRECONDITION (include/scsfm_hip.h): tables of a zoom-in resize with at most 5 taps, so that a tile's window spans
   // at most kAugSrcRows x kAugSrcCols source pixels.  Tables that break it (the C entry point takes any) must not
-  // reach beyond the two LDS arrays: the row count, every window column and every tap row are clamped -- such a call
-  // returns meaningless pixels, not a fault.
+  // reach beyond the two LDS arrays nor outside [frames, frames + bytes): the row count, every window column, every tap
+  // row and the window's first row / column are clamped, and the dword loads are guarded at both ends of the buffer --
+  // such a call returns meaningless pixels, not a fault.
   const int c0 = flip ? W - h1 : h0;  // (columns: h1 - h0 <= 64 + 5)
   const int nrows = v1 - v0 < 0 ? 0 : (v1 - v0 > kAugSrcRows ? kAugSrcRows : v1 - v0);
   const uint8_t* __restrict__ src = frames + (size_t)f * H * W * 3;
@@ -71,11 +81,11 @@ __global__ __launch_bounds__(kThreads) void augment_kernel(int T, int H, int W, 
     const int nd = kAugRowBytes / 4;
     for (int i = threadIdx.x; i < nrows * nd; i += kThreads) {
       const int r = i / nd, d = i - r * nd;
-      const uint8_t* first = src + ((size_t)(v0 + r) * W + c0) * 3;      // first byte of the window in this row
+      const uint8_t* first = aug_row_first(src, v0 + r, c0, H, W);       // first byte of the window in this row
       const uint8_t* a = first - (reinterpret_cast<size_t>(first) & 3) + 4 * (size_t)d;  // aligned dword d of the row
       uint32_t w = 0;
-      if (a + 4 <= buf_end) w = *reinterpret_cast<const uint32_t*>(a);
-      else for (int k = 0; k < 4; ++k) if (a + k < buf_end) w |= uint32_t(a[k]) << (8 * k);  // the buffer's last bytes
+      if (a >= frames && a + 4 <= buf_end) w = *reinterpret_cast<const uint32_t*>(a);
+      else for (int k = 0; k < 4; ++k) if (a + k >= frames && a + k < buf_end) w |= uint32_t(a[k]) << (8 * k);  // the buffer's first / last bytes
       sSrc[r][d] = w;
     }
   }
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void augment_kernel(int T, int H, int W, 
 #pragma unroll
     for (int i = 0; i < 5; ++i) k[i] = i < hcnt ? hb[2 + i] : 0;
     for (int r = wave; r < nrows; r += kThreads / kWave) {
-      const unsigned skew = unsigned(reinterpret_cast<size_t>(src + ((size_t)(v0 + r) * W + c0) * 3) & 3);  // the window's first byte inside its first dword
+      const unsigned skew = unsigned(reinterpret_cast<size_t>(aug_row_first(src, v0 + r, c0, H, W)) & 3);  // the window's first byte inside its first dword
       const uint8_t* __restrict__ row = reinterpret_cast<const uint8_t*>(&sSrc[r][0]) + skew;
       int h[3] = {1 << (kAugPrec - 1), 1 << (kAugPrec - 1), 1 << (kAugPrec - 1)};
 #pragma unroll

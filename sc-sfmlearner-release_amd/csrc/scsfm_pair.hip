@@ -660,7 +660,12 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
   __shared__ Cell win[kWinH][kWinW];  // staging window of the scatter into dL/d ref_depth
   if (T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0)) return;  // as in pass A
   const T ca = t_abs(T(sums[5]) * g_photo[0]), cb_ = t_abs(T(sums[6]) * g_geom[0]);
-  const T unit = sizeof(T) == 4 ? (ca > cb_ ? ca : cb_) : T(1), inv_unit = T(1) / unit;
+  // What this pass scatters is dL/d diff_depth = b m - [mask] a m blend: without the weight mask only the geometry
+  // coefficient is in it, so the unit is |b| alone (with |a| >> |b| the cells would otherwise resolve |b|-sized values
+  // with 2^-20 |a|: per cents).  A unit of 0 (nothing to scatter) or in the subnormal range (1 / unit overflows) is
+  // raised to FLT_MIN: the staged values then stay finite and at most as large as with the true unit.
+  const T want = (flags & SCSFM_WITH_MASK) ? (ca > cb_ ? ca : cb_) : cb_;
+  const T unit = sizeof(T) == 4 ? (want > T(1.17549435e-38f) ? want : T(1.17549435e-38f)) : T(1), inv_unit = T(1) / unit;
   if (spec_valid(sums, g_photo, g_geom)) return;  // the speculative forward already ran this pass in its tail
   const int px = blk.x * kWave + (threadIdx.x & (kWave - 1));
   const int py0 = (blk.y * (kThreads / kWave) + threadIdx.x / kWave) * ROWS;

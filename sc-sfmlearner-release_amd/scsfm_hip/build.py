@@ -46,15 +46,19 @@ def deps():
         [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "scsfm_hip.h")]
 
 
-def source_id():
+def source_id(extra=()):
     """First 16 hex digits of the sha256 over everything the library is built from: every source file (names and
-    contents, sorted) and the compiler flags / target architecture.  It is compiled into the binary (scsfm_source_id)
-    so that a loaded .so can be tied to the sources next to it."""
+    contents, sorted) and the compiler flags / target architecture -- including any ``extra`` flags (-D tuning knobs)
+    of a non-default build, so that a tuning variant can never carry the default library's id (bench.py ties PMC
+    counters to a library by this id).  It is compiled into the binary (scsfm_source_id) so that a loaded .so can be
+    tied to the sources next to it."""
     h = hashlib.sha256()
     for path in deps():
         h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
     h.update(" ".join(FLAGS).encode())
+    if extra:
+        h.update(b"\0extra:" + " ".join(extra).encode())
     return h.hexdigest()[:16]
 
 
@@ -93,8 +97,11 @@ def _build_lock():
 def build(force=False, verbose=True, extra=()):
     """Compile every .hip file under csrc/ into one shared object.  Raises on failure.  Returns the library's path.
     Without ``force`` nothing is compiled when the binary in place already carries the tree's source id -- also when
-    that became true while this process was waiting for the lock (N ranks asking at once: one compiles)."""
-    want = source_id()
+    that became true while this process was waiting for the lock (N ranks asking at once: one compiles).  ``extra``:
+    further compiler flags (tuning knobs); the binary then carries source_id(extra), which differs from the tree's
+    default id, so the loader treats it as stale for the default configuration and rebuilds on the next plain get()."""
+    extra = tuple(extra)
+    want = source_id(extra)
     if not force and binary_source_id(LIB) == want:
         return LIB
     with _build_lock():

@@ -132,3 +132,14 @@ def test_graph_capture_needs_a_device():
     from scsfm_hip.graphs import GraphedStep
     with pytest.raises(RuntimeError):
         GraphedStep(lambda: None)
+
+
+def test_tuning_flags_change_the_source_id():
+    """build(extra=...) binaries carry an id of their own (round-4 advisor finding: bench.py's counter check took a
+    tuning variant for the default library)."""
+    from scsfm_hip import build
+    base = build.source_id()
+    assert build.source_id(()) == base
+    v = build.source_id(("-DSCSFM_WIN_W=80",))
+    assert v != base and len(v) == 16 and build.source_id(("-DSCSFM_WIN_W=80",)) == v
+    assert build.source_id(("-DSCSFM_WIN_W=64",)) != v

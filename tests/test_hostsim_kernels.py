@@ -468,6 +468,32 @@ def test_large_gradients_bypass_the_fixed_point_window(lib):
     assert _rel(g_td[0].double(), td64[0].grad) < 1e-3
 
 
+@pytest.mark.parametrize("with_mask,up", [(1, (1.0, 1e-4)), (0, (1.0, 1e-4)), (0, (1e-30, 1e-34)), (1, (3e-33, 1e-37))])
+def test_fallback_scatter_with_very_different_or_tiny_coefficients_fp32(lib, with_mask, up):
+    """The fallback geometry pass (no / failed speculation) stages its scatter in fixed-point cells counted in units of
+    the pair's own coefficient.  Round-4 advisor finding: with w_geom << w_photo and no weight mask the scattered
+    values are |b|-sized while the unit was max(|a|, |b|) -- 6e-4 of rounding in the median entry, 1.3 % in the worst --,
+    and a unit in the subnormal range made 1 / unit infinite.  ONE pair-direction (compute_pairwise_loss), so that
+    dL/d ref_depth is the scatter alone; fp32 kernels against the fp64 oracle, entries above 5 % of the map's scale."""
+    B, H, W = 4, 72, 100
+    d = synth.make_batch(B, H, W, n_ref=1, seed=63, depth="smooth")
+    ti, K, ri = d["tgt_img"], d["intrinsics"], d["ref_imgs"][0]
+    td, rd, po = d["tgt_depth"][0], d["ref_depths"][0][0], d["poses"][0]
+    c = lambda x: x.double()
+    td64, rd64 = leaf(c(td)), leaf(c(rd))
+    p, g = O.pairwise_loss(c(ti), c(ri), td64, rd64, c(po), c(K), 1, with_mask, 1, "zeros")
+    (up[0] * p + up[1] * g).backward()
+    fl = capi.make_flags(1, with_mask, 1, "zeros")
+    _, ws = capi.pair_fwd(lib, ti, ri, td, rd, po, K, fl)
+    _, g_rd, _ = capi.pair_bwd(lib, ti, ri, td, rd, po, K, fl, ws, torch.tensor([up[0]]), torch.tensor([up[1]]))
+    want, got = rd64.grad, g_rd.double()
+    assert bool(torch.isfinite(got).all())
+    big = want.abs() > 0.05 * float(want.abs().max())
+    rel = ((got - want).abs() / want.abs())[big]
+    assert int(big.sum()) > 1000 and float(rel.median()) < 3e-5 and float(rel.quantile(0.9)) < 1e-4, \
+        (float(rel.median()), float(rel.quantile(0.9)))
+
+
 def test_coarse_maps_of_unsupported_shapes(lib, monkeypatch):
     """A coarser scale that is not an exact power-of-two reduction is up-sampled by F.interpolate in the shim (as the
     reference does) and still matches the oracle; maps of different scales within one pair are rejected by the
