@@ -47,6 +47,13 @@ extern "C" {
 #define SCSFM_DEBUG_X3 4096u  /* no 12-value block reduction / gP atomics */
 #define SCSFM_DEBUG_X4 8192u  /* speculative forward: skip the per-pixel work of the geometry tail */
 #define SCSFM_DEBUG_X5 32768u /* scatter into the LDS window but never flush it */
+/* Debugging (results unchanged, runtime-flag instantiation, slower): scsfm_pairs_fwd (speculative forward) and
+ * scsfm_pairs_bwd (the fallback geometry pass) count every signed wrap of a fixed-point cell of their scatter windows
+ * (csrc/scsfm_geom.h: a cell holds +-2048 units; more than 32 near-cap pixels of one tile on one reference texel wrap
+ * it) in a word of pair i's workspace (byte 256 * B + 104 of d[i].ws; cleared by every scsfm_pairs_fwd); the forward
+ * also reports its count in out_i[7].  Intermediate wraps that cancel again are counted too: a count of 0 proves the
+ * cells held, a non-zero count means the depth gradients of the step may be off by multiples of 4096 units. */
+#define SCSFM_DEBUG_CHECK_WINDOW 65536u
 
 #define SCSFM_DEBUG_KERNEL_ONLY 16384u /* scsfm_pairs_fwd only, for timing: launch the main kernel alone (the
                                           constants of an earlier identical call are still in `ws`) */

@@ -546,7 +546,16 @@ __device__ __forceinline__ void lds_add(T* p, T v) {
 // Range: a pixel whose (unscaled) gradient reaches kFixCap does not enter the window at all -- it takes the direct
 // fp32 atomics that taps outside the window take -- so a cell wraps only if more than 2048 / kFixCap = 32 pixels of
 // ONE tile (each just below the cap; typical magnitudes are below 10) pile their taps onto the same reference pixel:
-// an areal compression of the warp that no frame-to-frame motion produces.
+// an areal compression of the warp that no frame-to-frame motion produces -- but that the operator does not reject (a
+// scene scaled down a hundredfold with a forward motion of several depths and a photo-only upstream gradient wraps
+// cells: tests/test_hostsim_kernels.py).  Two guards: tiles whose whole footprint covers fewer than kCompressiveCells
+// cells bypass the window (uniform branch per tile), and launches with SCSFM_DEBUG_CHECK_WINDOW count every wrap
+// exactly (win_add) in a word of the pair's workspace; the Python wrapper raises on a non-zero count when
+// SCSFM_CHECK_WINDOW=1.
+#ifndef SCSFM_COMPRESSIVE_CELLS  // knob for the tests: 0 = no guard (the wrap detector of the debug launches then has something to find)
+#define SCSFM_COMPRESSIVE_CELLS 128
+#endif
+constexpr int kCompressiveCells = SCSFM_COMPRESSIVE_CELLS;  // tiles whose scatter footprint is smaller than this bypass the window (spec_tile, geom_tile)
 constexpr float kFixScale = 1048576.0f;
 constexpr float kFixInv = 1.0f / 1048576.0f;
 constexpr float kFixCap = 64.0f;
@@ -572,9 +581,21 @@ __device__ __forceinline__ float win_unit(const int*, float g) { return g * kFix
 __device__ __forceinline__ double win_unit(const double*, double g) { return g; }
 __device__ __forceinline__ float win_unit(const float*, float g) { return g; }
 // ... added to a cell
-__device__ __forceinline__ void win_add(int* p, float units) { lds_add(p, cvt_round_half_up(units)); }
-__device__ __forceinline__ void win_add(double* p, double v) { lds_add(p, v); }
-__device__ __forceinline__ void win_add(float* p, float v) { lds_add(p, v); }  // (float cells: see geom_tile)
+// `ovf` (SCSFM_DEBUG_CHECK_WINDOW launches only; nullptr -- a compile-time constant in the product instantiation --
+// otherwise): the add returns the cell's previous value and a signed 32-bit wrap is counted in *ovf (a global word of
+// the pair's workspace).  Exact: every wrap of a cell is seen, at the price of a returning LDS atomic.
+__device__ __forceinline__ void win_add(int* p, float units, unsigned* ovf = nullptr) {
+  const int add = cvt_round_half_up(units);
+  if (ovf) {
+    const int old = __hip_atomic_fetch_add(p, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int sum = int(unsigned(old) + unsigned(add));
+    if (((old ^ sum) & (add ^ sum)) < 0) atomicAdd(ovf, 1u);
+  } else {
+    lds_add(p, add);
+  }
+}
+__device__ __forceinline__ void win_add(double* p, double v, unsigned* = nullptr) { lds_add(p, v); }
+__device__ __forceinline__ void win_add(float* p, float v, unsigned* = nullptr) { lds_add(p, v); }  // (float cells: see geom_tile)
 __device__ __forceinline__ float win_value(int c) { return float(c) * kFixInv; }
 __device__ __forceinline__ double win_value(double c) { return c; }
 __device__ __forceinline__ float win_value(float c) { return c; }
@@ -604,7 +625,8 @@ __device__ __forceinline__ int wide_adjust(const WideWin& ww, int ly) {  // only
 template <typename T, typename Cell, int WW, int WH>
 __device__ __forceinline__ void scatter_taps_window(Cell (*win)[WW], int wx0, int wy0,
                                                     T* __restrict__ gplane, const Sample<T>& s, T g,
-                                                    const WideWin& ww = WideWin{WH, 0, 0}, T inv_unit = T(1)) {
+                                                    const WideWin& ww = WideWin{WH, 0, 0}, T inv_unit = T(1),
+                                                    unsigned* ovf = nullptr) {
   if (g == T(0)) return;
   const int lx = s.xa - wx0, ly = s.ya - wy0;
   if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < ww.rows - 1 && win_fits(&win[0][0], g * inv_unit)) {
@@ -613,10 +635,10 @@ __device__ __forceinline__ void scatter_taps_window(Cell (*win)[WW], int wx0, in
     Cell* rn = &win[0][0] + ly * WW + lx;
     Cell* rs = rn + WW;
     if (ww.rows > WH) { rn += wide_adjust<WH>(ww, ly); rs += wide_adjust<WH>(ww, ly + 1); }  // (uniform branch)
-    win_add(rn, gu * s.wp[0]);
-    win_add(rn + 1, gu * s.wp[1]);
-    win_add(rs, gu * s.wp[2]);
-    win_add(rs + 1, gu * s.wp[3]);
+    win_add(rn, gu * s.wp[0], ovf);
+    win_add(rn + 1, gu * s.wp[1], ovf);
+    win_add(rs, gu * s.wp[2], ovf);
+    win_add(rs + 1, gu * s.wp[3], ovf);
   } else {
     scatter_taps(gplane, s, g);
   }
@@ -770,7 +792,7 @@ template <typename T, typename Cell, int WW, int WH>
 __device__ __forceinline__ T geom_consume(const BatchConsts<T>& bc, const GeomTaps<T>& f, int px, int py, T d, const T (&gI)[3], T g_dd,
                                           int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
                                           T* __restrict__ scatter_plane, T* acc, const WideWin& ww = WideWin{WH, 0, 0},
-                                          T inv_unit = T(1)) {
+                                          T inv_unit = T(1), unsigned* ovf = nullptr) {
   const Sample<T>& s = f.s;
   const TapRows<T>(&tc)[3] = f.tc;
   const TapRows<T>& td = f.td;
@@ -793,17 +815,17 @@ __device__ __forceinline__ T geom_consume(const BatchConsts<T>& bc, const GeomTa
   t.s.b = gI[0] * tc[0].s.b + gI[1] * tc[1].s.b + gI[2] * tc[2].s.b + gDp * td.s.b;
   T gix, giy;
   tap_rows_grad(t, s, gix, giy);
-  if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, Cell, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp, ww, inv_unit);
+  if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, Cell, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp, ww, inv_unit, ovf);
   return pixel_geometry_bwd(bc, s, px, py, d, gix, giy, gZ, H, W, acc);
 }
 template <typename T, typename Cell, int WW, int WH, typename Map>
 __device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py, T d, const T (&gI)[3], T g_dd,
                                         const T* __restrict__ ref_img, const Map& ref_depth,
                                         unsigned plane, int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
-                                        T* __restrict__ scatter_plane, T* acc, T inv_unit = T(1)) {
+                                        T* __restrict__ scatter_plane, T* acc, T inv_unit = T(1), unsigned* ovf = nullptr) {
   const GeomTaps<T> f = geom_fetch(bc, px, py, d, ref_img, ref_depth, plane, H, W, flags);
   return geom_consume<T, Cell, WW, WH>(bc, f, px, py, d, gI, g_dd, H, W, flags, win, wx0, wy0, scatter_plane, acc,
-                                       WideWin{WH, 0, 0}, inv_unit);
+                                       WideWin{WH, 0, 0}, inv_unit, ovf);
 }
 
 }  // namespace scsfm

@@ -109,6 +109,13 @@ __device__ __forceinline__ unsigned* finalize_counter(const PairBatch<T>& pb) {
   return reinterpret_cast<unsigned*>(pb.p[0].sums + 12);
 }
 
+// "cells of the scatter window that wrapped" counter of a pair (SCSFM_DEBUG_CHECK_WINDOW launches): another spare word
+// of its sums block.  Zeroed with the per-image constants, reported in out[7] by the finalize kernel.
+template <typename T>
+__device__ __forceinline__ unsigned* window_overflow_counter(const PairArgs<T>& pa) {
+  return reinterpret_cast<unsigned*>(pa.sums + 13);
+}
+
 // prep_kernel over every (pair, batch element).
 template <typename T>
 __global__ void pairs_prep_kernel(PairBatch<T> pb, int n, int B, const T* __restrict__ K) {
@@ -116,6 +123,7 @@ __global__ void pairs_prep_kernel(PairBatch<T> pb, int n, int B, const T* __rest
   if (i >= n * B) return;
   if (i == 0) *finalize_counter(pb) = 0u;
   const int pair = i / B, b = i - pair * B;
+  if (b == 0) *window_overflow_counter(pb.p[pair]) = 0u;
   prep_one(b, pb.p[pair].pose, K, pb.p[pair].consts);
 }
 
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_FWD_BLOCKS : 1) vo
 
 // The gates and divisions of mean_on_mask (loss_functions.py:123-129) on the three sums; also
 // publishes the coefficients the backward multiplies the upstream gradients with.
-// out[8] = {photo, geom, S_photo, S_geom, S_mask, 0, 0, 0}
+// out[8] = {photo, geom, S_photo, S_geom, S_mask, 0, 0, wrapped window cells (debug launches; else 0)}
 template <typename T>
 __device__ __forceinline__ void publish_losses(double Sp, double Sg, double Sm, double* __restrict__ sums,
                                                T* __restrict__ out) {
@@ -307,6 +315,7 @@ __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb
   block_sum<3>(v, red);
   if (threadIdx.x == 0) {
     publish_losses(v[0], v[1], v[2], sums, out);
+    out[7] = T(*window_overflow_counter(pa));  // (0 unless the forward was launched with SCSFM_DEBUG_CHECK_WINDOW and a cell wrapped)
     if (hint && spec != 0.0) {  // the weights the speculative forward read from the device (scsfm_pair_desc::hint)
       w_photo = hint[0]; w_geom = hint[1];
       if (w_photo == 0.0) spec = 0.0;  // nothing to factor out: the backward runs its own passes
@@ -686,6 +695,18 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
   int wx0, wy0;
   window_origin<T, kWinW, kWinH>(bc, blk.x * kWave + kWave / 2, blk.y * (kThreads / kWave) * ROWS + 2 * ROWS, tgt_depth,
                                  H, W, flags, wx0, wy0);
+  if (sizeof(Cell) == 4) {
+    // The guard of the speculative forward's window (scsfm_spec_tile.h: scatter_box) for this pass, which has no
+    // bounding box of its taps: two opposite corners of the tile are projected; if both land inside the reference view
+    // within a footprint of fewer than kCompressiveCells cells, the warp compresses the tile's 1024 pixels so much that
+    // a fixed-point cell could wrap -- the tile then scatters with direct fp32 atomics (window out of every tap's reach).
+    const int x0 = blk.x * kWave, y0 = blk.y * (kThreads / kWave) * ROWS;
+    const int x1 = t_clampi(x0 + kWave - 1, 0, W - 1), y1 = t_clampi(y0 + (kThreads / kWave) * ROWS - 1, 0, H - 1);
+    const Sample<T> c0 = project_pixel(bc, x0, y0, tgt_depth.at(x0, y0, (unsigned(y0) * unsigned(W) + unsigned(x0)) * unsigned(sizeof(T))), H, W, flags);
+    const Sample<T> c1 = project_pixel(bc, x1, y1, tgt_depth.at(x1, y1, (unsigned(y1) * unsigned(W) + unsigned(x1)) * unsigned(sizeof(T))), H, W, flags);
+    const int ex = (c1.xa > c0.xa ? c1.xa - c0.xa : c0.xa - c1.xa) + 2, ey = (c1.ya > c0.ya ? c1.ya - c0.ya : c0.ya - c1.ya) + 2;
+    if (c0.valid && c1.valid && ex * ey < kCompressiveCells) wx0 = 1 << 28;
+  }
   T acc[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) acc[i] = T(0);
@@ -708,7 +729,8 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
     if (px >= W || py >= H) continue;
     const T gI[3] = {in_g[r][0], in_g[r][1], in_g[r][2]};
     const T gd = geom_pixel<T, Cell, kWinW, kWinH>(bc, px, py, in_d[r], gI, in_g[r][3], ref_img, ref_depth, plane, H, W, flags,
-                                             win, wx0, wy0, g_scatter, acc, inv_unit);
+                                             win, wx0, wy0, g_scatter, acc, inv_unit,
+                                             (flags & SCSFM_DEBUG_CHECK_WINDOW) ? window_overflow_counter(pa) : nullptr);
     st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), (flags & SCSFM_DEBUG_X2) ? T(0) : gd);
   }
   __syncthreads();
@@ -1076,6 +1098,7 @@ __global__ __launch_bounds__(kThreads) void pairs_zero_prep_kernel(PairBatch<T> 
       if (threadIdx.x == 0) *finalize_counter(pb) = 0u;
       for (int i = threadIdx.x; i < npairs * B; i += kThreads) {
         const int pair = i / B, b = i - pair * B;
+        if (b == 0) *window_overflow_counter(pb.p[pair]) = 0u;
         prep_one(b, pb.p[pair].pose, K, pb.p[pair].consts);
       }
     }

@@ -244,6 +244,13 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     wx0 = ex <= WW ? x0 - (WW - ex) / 2 : (x0 + x1 + 1) / 2 - WW / 2;
     wy0 = ey <= wrows ? y0 - (wrows - ey) / 2 : (y0 + y1 + 1) / 2 - wrows / 2;
     cx0 = x0 - wx0; cx1 = x1 + 1 - wx0; cy0 = y0 - wy0; cy1 = y1 + 1 - wy0;
+    // A tile whose taps all land on fewer than kCompressiveCells cells (the 868 pixels of a tile on < 128 texels: an areal
+    // compression of about 7 or more; a cell wraps from 32 near-cap pixels) could pile enough near-cap terms on one
+    // fixed-point cell to wrap it (+-2048 units:
+    // scsfm_geom.h; reachable with a scene scaled down a hundredfold and a forward motion of several depths -- tests).
+    // Such a tile does without the window: it is moved out of every tap's reach, so all of them take the direct fp32
+    // atomics and the flush finds an empty region (cx0 + wx0, what the staging uses, is unchanged).
+    if (sizeof(Cell) == 4 && ex * ey < kCompressiveCells) { wx0 -= 1 << 28; cx0 += 1 << 28; cx1 += 1 << 28; }
   };
   // kStage (fp32 + SSIM): the texels the geometry tail samples -- the reference view's colours and depth around
   // where the tile lands -- are staged in LDS at the start of the tail: the colour planes behind the parked
@@ -435,6 +442,9 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     T acc[12], gd[STRIP];
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = T(0);
+    // debugging launches count the wraps of the window's fixed-point cells (scsfm_geom.h: win_add); flags is a
+    // compile-time constant without that bit in the product instantiation, so this is a constant nullptr there
+    unsigned* const ovf = (flags & SCSFM_DEBUG_CHECK_WINDOW) ? window_overflow_counter(pa) : nullptr;
 #pragma unroll
     for (int k = 0; k < STRIP; ++k) {
       const int ly = strip * STRIP + k, py = py0 + k;
@@ -447,10 +457,11 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
       }
       if constexpr (kStage) {
         const GeomTaps<T> f = geom_fetch<kStageRows, !kLean>(bc, px, py, d_own[k], refP, ref_depth, H, W, flags, staged);
-        gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, d_own[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc, ww);
+        gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, d_own[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc, ww,
+                                              T(1), ovf);
       } else {
         gd[k] = geom_pixel<T, Cell, WW, WH>(bc, px, py, d_own[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
-                                      wy0, g_scatter, acc);
+                                      wy0, g_scatter, acc, T(1), ovf);
       }
     }
     // A barrier waits for every outstanding global store / atomic of the wave, so everything that writes to

@@ -368,8 +368,15 @@ def _pair_list(tgt_img, ref_imgs, tgt_depths, ref_depths, poses, poses_inv):
     return pairs
 
 
+DEBUG_CHECK_WINDOW = 65536  # SCSFM_DEBUG_CHECK_WINDOW (include/scsfm_hip.h)
+
+
+class WindowOverflow(RuntimeError):
+    """A fixed-point cell of the speculative forward's scatter window wrapped (SCSFM_CHECK_WINDOW=1 runs only)."""
+
+
 def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, group=None,
-                       hint=None, ws=None, hint_dev=None):
+                       hint=None, ws=None, hint_dev=None, check_window=False):
     """All pair-directions of loss_functions.py:56-90 in ONE call into the library.  ``tgt_depths[s]``
     and ``ref_depths[i][s]`` are full-resolution maps or, for a coarser scale, [B, 1, H >> k, W >> k] maps that the
     kernels read through the nearest up-sampling's index map (`depth_shift`).  Returns (photo, geom, outs [n_pairs, 8], ws)
@@ -381,6 +388,10 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
     tensor on the device holding that pair (scsfm_pair_desc::hint): the kernels read it instead of the host values, and
     photo_geometry_bwd -- given the same tensor -- leaves the upstream gradients it saw in it, so that the next
     forward speculates on the weights the training loop really uses.
+
+    ``check_window`` (debugging; config.check_window(), i.e. SCSFM_CHECK_WINDOW=1): the speculative forward runs with
+    SCSFM_DEBUG_CHECK_WINDOW -- the runtime-flag instantiation, every add into the scatter window a returning atomic --
+    and this call synchronises and raises WindowOverflow if a cell wrapped (the gradients it would produce are wrong).
 
     ``group``: a torch.distributed process group -> exact data-parallel mode: the three raw sums of
     every pair are all-reduced (one [n_pairs, 3] collective) and the masked means are re-evaluated on
@@ -416,8 +427,15 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         d.ws, d.out = wp + j * stride, op + j * esz
         d.gbuf = wp + j * stride + ws_bytes if spec else None
         d.depth_shift = shifts[j]
-    lib.call(f"scsfm_pairs_fwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags,
+    lib.call(f"scsfm_pairs_fwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K),
+             flags | (DEBUG_CHECK_WINDOW if check_window else 0),
              float(hint[0]) if spec else 0.0, float(hint[1]) if spec else 0.0, _stream(tgt_img))
+    if check_window:
+        wrapped = int(outs[:n, 7].sum().item())  # (synchronises: a debugging mode)
+        if wrapped:
+            raise WindowOverflow(f"scsfm_hip: {wrapped} fixed-point cell(s) of the scatter window wrapped -- more than 32 "
+                                 "near-cap pixels of one tile land on one reference pixel (an extremely compressive warp); "
+                                 "the depth gradients of this step would be wrong")
     if group is not None:
         import torch.distributed as dist
         sums = outs[:n, 2:5].contiguous()
@@ -434,8 +452,16 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
     return outs[n, 0], outs[n, 1], outs[:n], ws
 
 
+def window_overflows(lib, ws, n_pairs, B, H, W, spec=True):
+    """Wraps of fixed-point scatter cells counted by launches with SCSFM_DEBUG_CHECK_WINDOW since the last forward on
+    ``ws`` (one int per pair-direction; reads the device: synchronises)."""
+    ws_bytes, scratch_bytes, _ = _sizes(lib, B, H, W)
+    stride = ws_bytes + (scratch_bytes if spec else 0)
+    return [int(ws[j * stride + 256 * B + 104:j * stride + 256 * B + 108].view(torch.int32).item()) for j in range(n_pairs)]
+
+
 def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws, g_photo,
-                       g_geom, hint_dev=None, need_imgs=None, need_K=False, smooth=None):
+                       g_geom, hint_dev=None, need_imgs=None, need_K=False, smooth=None, check_window=False):
     """Gradients of photo_geometry_fwd's two sums: (g_tgt_depths[s], g_ref_depths[i][s], g_poses[i],
     g_poses_inv[i]).  Each depth map's gradient buffer receives the sum over every pair-direction that
     touches it (dense as target, scattered as reference) from the library's combining kernel, which
@@ -485,6 +511,7 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         d.gbuf = wp + j * stride + ws_bytes if spec else None
         d.g_tgt_depth, d.g_ref_depth, d.g_pose = gbuf(kt).data_ptr(), gbuf(kr).data_ptr(), gp + j * psz
         d.depth_shift = _pair_shift(dt, dr, B, H, W)
+    bflags = flags | (DEBUG_CHECK_WINDOW if check_window else 0)
     if smooth is not None:
         sws, g_smooth = smooth
         nf = 1 + len(ref_depths)
@@ -495,11 +522,16 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         grads = _ptr_array(frames)
         edges = (_ct.c_void_p * nf)(*[sws.data_ptr() + nf * sw_bytes + i * plane_bytes for i in range(nf)])
         stats = (_ct.c_void_p * nf)(*[sws.data_ptr() + i * sw_bytes for i in range(nf)])
-        lib.call(f"scsfm_pairs_bwd_smooth_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags, _p(scratch),
+        lib.call(f"scsfm_pairs_bwd_smooth_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), bflags, _p(scratch),
                  _p(g_photo), _p(g_geom), nf, grads, edges, stats, _p(g_smooth), _stream(tgt_img))
     else:
-        lib.call(f"scsfm_pairs_bwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), flags, _p(scratch),
+        lib.call(f"scsfm_pairs_bwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), bflags, _p(scratch),
                  _p(g_photo), _p(g_geom), _stream(tgt_img))
+    if check_window:  # (debugging: the fallback geometry pass counts into the same words; synchronises)
+        wrapped = sum(window_overflows(lib, ws, n, B, H, W, spec))
+        if wrapped:
+            raise WindowOverflow(f"scsfm_hip: fixed-point cells of a scatter window wrapped {wrapped} time(s) in this step's "
+                                 "forward / backward (an extremely compressive warp): depth gradients may be off")
     g_inputs = None
     if need_imgs is not None or need_K:
         # gradients of the data inputs (scsfm_pairs_bwd_inputs): images accumulate, intrinsics are stored

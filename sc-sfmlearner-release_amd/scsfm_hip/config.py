@@ -45,3 +45,11 @@ def hint_tensor(device):
         t = torch.tensor(_hint, dtype=torch.float64, device=device)
         _hint_dev[key] = t
     return t
+
+
+def check_window():
+    """SCSFM_CHECK_WINDOW=1 (debugging): every speculative forward counts wraps of its fixed-point scatter cells and the
+    call raises capi.WindowOverflow if there are any (synchronises; the runtime-flag kernel instantiation).  Read per
+    call."""
+    import os
+    return os.environ.get("SCSFM_CHECK_WINDOW") == "1"

@@ -63,7 +63,8 @@ class PhotoGeometryLoss(torch.autograd.Function):
         # the pair the kernels speculate on lives on the device: every backward leaves the upstream gradients it saw there
         hint_dev = _config.hint_tensor(tgt_img.device) if hint is not None else None
         photo, geom, _, ws = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
-                                                     poses_inv, group=_dist.exact_group(), hint=hint, hint_dev=hint_dev)
+                                                     poses_inv, group=_dist.exact_group(), hint=hint, hint_dev=hint_dev,
+                                                     check_window=hint is not None and _config.check_window())
         ctx.flags, ctx.n_ref, ctx.n_scales = flags, n_ref, n_scales
         ctx.hint_dev = hint_dev
         ctx.save_for_backward(tgt_img, K, *rest, ws)
@@ -71,6 +72,7 @@ class PhotoGeometryLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_photo, g_geom):
+        from . import config as _config
         lib = _lib.get()
         n_ref, n_scales, flags = ctx.n_ref, ctx.n_scales, ctx.flags
         saved = ctx.saved_tensors
@@ -84,7 +86,7 @@ class PhotoGeometryLoss(torch.autograd.Function):
         res = capi.photo_geometry_bwd(
             lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws,
             _scalar(g_photo, tgt_img), _scalar(g_geom, tgt_img), hint_dev=ctx.hint_dev,
-            need_imgs=need_imgs if any(need_imgs) else None, need_K=need_K)
+            need_imgs=need_imgs if any(need_imgs) else None, need_K=need_K, check_window=_config.check_window())
         g_td, g_rd, g_poses, g_poses_inv = res[:4]
         g_imgs, g_K = res[4:] if len(res) > 4 else ([None] * (1 + n_ref), None)
         return (None, None, None, g_imgs[0], g_K, *g_imgs[1:], *g_td, *[g for r in g_rd for g in r], *g_poses,
@@ -173,8 +175,10 @@ class StepLoss(torch.autograd.Function):
         _need_cuda(tgt_img, K, *rest)
         ref_imgs, tgt_depths, ref_depths, poses, poses_inv, _ = PhotoGeometryLoss._split(rest, n_ref, n_scales)
         hint = (float(np.float32(w_photo)), float(np.float32(w_geom))) if (w_photo != 0 and any(ctx.needs_input_grad)) else None
+        from . import config as _config
         photo, geom, _, ws = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
-                                                     poses_inv, group=_dist.exact_group(), hint=hint)
+                                                     poses_inv, group=_dist.exact_group(), hint=hint,
+                                                     check_window=hint is not None and _config.check_window())
         frames = [tgt_depths[0]] + [r[0] for r in ref_depths]
         imgs = [tgt_img] + list(ref_imgs)
         # (photo, geom) are elements 0 and 1 of one contiguous row -- the library's totals, or the exact mode's sums;
@@ -190,6 +194,7 @@ class StepLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, *_unused):
+        from . import config as _config
         lib = _lib.get()
         flags, n_ref, n_scales, w_photo, w_smooth, w_geom = ctx.cfg
         saved = ctx.saved_tensors
@@ -202,7 +207,7 @@ class StepLoss(torch.autograd.Function):
         # the smooth term's depth gradients ride along in the pass that stores the pair terms' (scsfm_pairs_bwd_smooth)
         res = capi.photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws,
                                       gw[0:1], gw[1:2], need_imgs=need_imgs if any(need_imgs) else None, need_K=need_K,
-                                      smooth=(sws, gw[2:3]))
+                                      smooth=(sws, gw[2:3]), check_window=_config.check_window())
         g_td, g_rd, g_poses, g_poses_inv = res[:4]
         g_imgs, g_K = res[4:] if len(res) > 4 else ([None] * (1 + n_ref), None)
         frames = [tgt_depths[0]] + [r[0] for r in ref_depths]

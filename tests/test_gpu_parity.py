@@ -394,6 +394,47 @@ def test_large_gradients_bypass_the_fixed_point_window(dev):
     assert _rel64(g_td[0].double(), td64[0].grad) < 1e-3
 
 
+@pytest.mark.parametrize("B,scale,tz,w_geom,hint", [
+    (2, 1.0, 1.0, 0.5, (1.0, 0.5)),    # the round-4 review's case: tz = +1, depth 0.1 .. 0.3, 2 x 72 x 100
+    (3, 1.0, 1.0, 0.5, (1.0, 0.5)),
+    (3, 0.03, 2.0, 0.0, (1.0, 0.0)),   # wrapped 66 cells of the speculative tail before round 5's guard (CPU simulation)
+    (2, 0.04, 2.0, 0.5, (1.0, 0.5)),   # geometry gate closed -> fallback passes; wrapped 8 cells of the geometry pass
+    (3, 0.04, 2.0, 0.0, None),         # no speculation: fallback passes
+])
+def test_compressive_warps_do_not_wrap_the_fixed_point_window(dev, B, scale, tz, w_geom, hint):
+    """Twin of tests/test_hostsim_kernels.py's test of the same name on the hardware: a scaled-down scene after a
+    forward motion of several depths (areal compression ~100, near-cap scatter terms) used to wrap the +-2048-unit
+    ds_add_u32 cells silently.  Debug launches count wraps exactly (returning LDS atomics): zero, and dL/d ref_depth
+    matches the fp64 oracle."""
+    from oracle import scsfm_oracle as O
+    from scsfm_hip import _lib, capi, synth
+    lib = _lib.get()
+    H, W = 72, 100
+    d = synth.make_batch(B, H, W, n_ref=1, seed=67, depth="smooth")
+    g = torch.Generator().manual_seed(5)
+    mk = lambda: (scale * (0.1 + 0.2 * torch.rand(B, 1, H, W, generator=g))).contiguous()
+    tds, rds = [mk()], [[mk()]]
+    p = torch.zeros(B, 6)
+    p[:, 2] = tz * scale
+    ti, K, ris = d["tgt_img"], d["intrinsics"], d["ref_imgs"]
+    c = lambda x: x.double()
+    lf = lambda x: x.double().clone().requires_grad_(True)
+    td64, rd64 = [lf(tds[0])], [[lf(rds[0][0])]]
+    po, go = O.photo_and_geometry_loss(c(ti), [c(ris[0])], c(K), td64, rd64, [c(p)], [c(-p)], 1, 1, 1, 1, "zeros")
+    (po + w_geom * go).backward()
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    v = lambda x: x.to(dev).contiguous()
+    a = (v(ti), v(K), [v(ris[0])], [v(tds[0])], [[v(rds[0][0])]], [v(p)], [v(-p)])
+    t = lambda x: torch.tensor([x], device=dev)
+    for check in (True, False):  # the debug launch (runtime-flag instantiation, returning atomics) and the product launch
+        photo, geom, outs, ws = capi.photo_geometry_fwd(lib, fl, *a, hint=hint, check_window=check and hint is not None)
+        assert abs(float(photo) - float(po)) < 1e-5 and abs(float(geom) - float(go)) < 1e-5
+        g_td, g_rd, _, _ = capi.photo_geometry_bwd(lib, fl, *a, ws, t(1.0), t(w_geom), check_window=check)
+        assert capi.window_overflows(lib, ws, 2, B, H, W, spec=hint is not None) == [0, 0]
+        assert _rel64(g_rd[0][0].double(), rd64[0][0].grad) < 1e-4, check
+        assert _rel64(g_td[0].double(), td64[0].grad) < 1e-4, check
+
+
 def test_boundary_functions(IW, dev):
     """pixel2cam / cam2pixel / cam2pixel2 / legacy inverse_warp (euler and quat) on the hardware, fp64 and fp32,
     values and gradients against the oracle (tests/_boundary_checks.py; CPU twin: tests/test_boundary_names.py)."""

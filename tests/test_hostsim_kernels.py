@@ -494,6 +494,78 @@ def test_fallback_scatter_with_very_different_or_tiny_coefficients_fp32(lib, wit
         (float(rel.median()), float(rel.quantile(0.9)))
 
 
+def _compressive_case(B, scale, tz, seed=67):
+    """A scene `scale` times smaller than usual (depths scale * 0.1 .. 0.3) seen after a forward motion of tz * scale:
+    every target pixel lands within 5 .. 13 % of its distance from the principal point -- an areal compression of ~100 --
+    while the unscaled per-pixel scatter terms 2 Z / (Z + D_p)^2 grow as 1 / scale."""
+    H, W = 72, 100
+    d = synth.make_batch(B, H, W, n_ref=1, seed=seed, depth="smooth")
+    g = torch.Generator().manual_seed(5)
+    mk = lambda: (scale * (0.1 + 0.2 * torch.rand(B, 1, H, W, generator=g))).contiguous()
+    tds, rds = [mk()], [[mk()]]
+    p = torch.zeros(B, 6)
+    p[:, 2] = tz * scale
+    return d["tgt_img"], d["intrinsics"], d["ref_imgs"], tds, rds, [p], [-p.clone()]
+
+
+@pytest.mark.parametrize("B,scale,tz,w_geom,hint", [
+    (2, 1.0, 1.0, 0.5, (1.0, 0.5)),    # the round-4 review's case: tz = +1, depth 0.1 .. 0.3, 2 x 72 x 100 (geometry gate closed)
+    (3, 1.0, 1.0, 0.5, (1.0, 0.5)),    # ... with both gates open
+    (3, 0.03, 2.0, 0.0, (1.0, 0.0)),   # scaled scene, photo-only upstream: wrapped 66 cells of the speculative tail before the guard
+    (2, 0.04, 2.0, 0.5, (1.0, 0.5)),   # geometry gate closed -> fallback passes: wrapped 8 cells of the geometry pass
+    (3, 0.04, 2.0, 0.0, None),         # no speculation: fallback passes (30 wraps before the guard)
+])
+def test_compressive_warps_do_not_wrap_the_fixed_point_window_fp32(lib, B, scale, tz, w_geom, hint):
+    """Round-4 review: the fixed-point scatter cells (+-2048 units) wrap SILENTLY if more than 32 near-cap pixels of one
+    tile pile on one reference texel.  Reachable (second half of the cases; errors of 70 .. 145 % of the map's scale were
+    measured before round 5).  Now a tile whose scatter footprint covers fewer than kCompressiveCells cells bypasses the
+    window, and debug launches (SCSFM_DEBUG_CHECK_WINDOW) count wraps exactly: here the count must be zero and
+    dL/d ref_depth must match the fp64 oracle."""
+    ti, K, ris, tds, rds, ps, pis = _compressive_case(B, scale, tz)
+    c = lambda x: x.double()
+    td64, rd64 = [leaf(c(tds[0]))], [[leaf(c(rds[0][0]))]]
+    po, go = O.photo_and_geometry_loss(c(ti), [c(ris[0])], c(K), td64, rd64, [c(ps[0])], [c(pis[0])], 1, 1, 1, 1, "zeros")
+    (po + w_geom * go).backward()
+    fl = capi.make_flags(1, 1, 1, "zeros")
+    photo, geom, outs, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=hint, check_window=hint is not None)
+    assert abs(float(photo) - float(po)) < 1e-5 and abs(float(geom) - float(go)) < 1e-5
+    g_td, g_rd, _, _ = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, torch.tensor([1.0]),
+                                               torch.tensor([w_geom]), check_window=True)  # (raises WindowOverflow on a wrap)
+    assert capi.window_overflows(lib, ws, 2, B, 72, 100, spec=hint is not None) == [0, 0]
+    assert _rel(g_rd[0][0].double(), rd64[0][0].grad) < 1e-4 and _rel(g_td[0].double(), td64[0].grad) < 1e-4
+
+
+def test_the_wrap_detector_fires_without_the_guard():
+    """The same scaled scene on a build WITHOUT the compressive-tile guard (-DSCSFM_COMPRESSIVE_CELLS=0, its own
+    simulation library): cells wrap, dL/d ref_depth is off by multiples of 4096 units, and the debug launch says so --
+    capi.photo_geometry_fwd(check_window=True) raises WindowOverflow.  (A subprocess: the simulation's build flags are
+    fixed at import.)"""
+    import os
+    import subprocess
+    import sys
+    code = """
+import sys, torch
+sys.path[:0] = [%r, %r, %r]
+from hostsim import harness
+from scsfm_hip import capi
+import test_hostsim_kernels as T
+lib = harness.lib()
+ti, K, ris, tds, rds, ps, pis = T._compressive_case(3, 0.03, 2.0)
+fl = capi.make_flags(1, 1, 1, "zeros")
+_, _, outs, ws = capi.photo_geometry_fwd(lib, fl | capi.DEBUG_CHECK_WINDOW, ti, K, ris, tds, rds, ps, pis, hint=(1.0, 0.0))
+n = capi.window_overflows(lib, ws, 2, 3, 72, 100)
+assert n[0] > 0 and n[1] == 0 and float(outs[0, 7]) == n[0], (n, outs[:, 7])
+try:
+    capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=(1.0, 0.0), check_window=True)
+except capi.WindowOverflow as e:
+    print("RAISED", n[0])
+""" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sc-sfmlearner-release_amd"))
+    env = dict(os.environ, HOSTSIM_EXTRA="-DSCSFM_COMPRESSIVE_CELLS=0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "RAISED" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
 def test_coarse_maps_of_unsupported_shapes(lib, monkeypatch):
     """A coarser scale that is not an exact power-of-two reduction is up-sampled by F.interpolate in the shim (as the
     reference does) and still matches the oracle; maps of different scales within one pair are rejected by the
