@@ -21,6 +21,8 @@ def main():
         ap.add_argument("--" + k.replace("_", "-"), type=int, default=v)
     ap.add_argument("--dataset", default="kitti")
     ap.add_argument("--depths", default="smooth,iid")
+    ap.add_argument("--extra", type=int, default=int(os.environ.get("VARIANT_EXTRA", "0")),
+                    help="1: also time the plain forward and the fallback backward")
     a = ap.parse_args()
     from scsfm_hip import _lib, capi
     import loss_functions as LF
@@ -44,6 +46,14 @@ def main():
         _, _, _, ws = capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, pp, pis, hint=(1.0, 0.5))
         fn = lambda: capi.photo_geometry_fwd(lib, fl | 16384, tgt, K, refs, tds, rds, pp, pis, hint=(1.0, 0.5), ws=ws)
         out["us"][depth] = [round(bench._event_time(fn, a.iters) * 1e6, 1) for _ in range(a.rounds)]
+        if a.extra:
+            # the plain forward (validation path: prep + pair_fwd_kernel + finalize) and the backward of the first step
+            # after a weight change (guards fail: pair_bwd_photo + pair_bwd_geom + combine)
+            one, third = torch.tensor([1.0], device=dev), torch.tensor([0.3], device=dev)
+            plain = lambda: capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, pp, pis, hint=None)
+            stale = lambda: capi.photo_geometry_bwd(lib, fl, tgt, K, refs, tds, rds, pp, pis, ws, one, third)
+            out.setdefault("us_plain_fwd", {})[depth] = [round(bench._event_time(plain, a.iters) * 1e6, 1) for _ in range(a.rounds)]
+            out.setdefault("us_fallback_bwd", {})[depth] = [round(bench._event_time(stale, a.iters) * 1e6, 1) for _ in range(a.rounds)]
     print(json.dumps(out))
 
 
