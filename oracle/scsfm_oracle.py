@@ -348,8 +348,18 @@ def depth_errors(gt, pred, dataset):
 # --------------------------------------------------------------------------------------------
 # Where an fp32 evaluation may legitimately differ from an fp64 one by more than round-off
 # --------------------------------------------------------------------------------------------
+def _sampling_slopes(src, xn, yn, padding_mode, delta_px=1e-3):
+    """|d sampled / d ix| + |d sampled / d iy| of bilinear_sample(src) at (xn, yn), per channel [B,C,H,W]: one-sided
+    differences over delta_px pixels (fp64), i.e. the slope of the bilinear patch the position lies in."""
+    _, _, H, W = src.shape
+    base = bilinear_sample(src, xn, yn, padding_mode, "explicit")
+    dx = bilinear_sample(src, xn + 2 * delta_px / W, yn, padding_mode, "explicit")
+    dy = bilinear_sample(src, xn, yn + 2 * delta_px / H, padding_mode, "explicit")
+    return ((dx - base).abs() + (dy - base).abs()) / delta_px
+
+
 def pairwise_gate_margins(tgt_img, ref_img, tgt_depth, ref_depth, pose, K, with_ssim, with_mask, with_auto_mask,
-                          padding_mode, eps_px=2e-3, eps_val=2e-4):
+                          padding_mode, eps_px=2e-3, eps_val=2e-4, eps_slope_px=5e-4):
     """The path is full of discontinuous gates (inverse_warp.py:219-224,264; loss_functions.py:99,101,104-105; the clamps
     of the SSIM module :42; the tap switch of grid_sample).  A pixel whose gate is decided by less than fp32 round-off
     can come out on the other side in ANY fp32 evaluation, the reference's own included, and then differs by its full
@@ -362,7 +372,14 @@ def pairwise_gate_margins(tgt_img, ref_img, tgt_depth, ref_depth, pose, K, with_
         own   [B,H,W] bool : only this pixel's own dense gradient is discontinuous (sampling position within eps of a
                              tap switch: the bilinear slope changes, values and scatter weights do not)
         xa, ya [B,H,W] long: north-west tap of the pixel (clamped into the image), for the scatter footprint
-    """
+
+    Round 5: the margins of the VALUE gates (clamps and sign of |It - Iw|, the auto-mask comparison, sign and clamp of the
+    depth inconsistency) grow with the local slope of what is sampled: a sampling position that differs by a few ulp of
+    the coordinate (6e-5 px at x = 800; rcp against division, the fused projection) moves the sampled value by slope x
+    that difference, and on iid inputs -- depth steps of up to 100 and colour steps of up to 4 between neighbouring
+    texels -- that is 10 .. 1000 times eps_val.  The 20 worst judged entries of round 4's iid case were exactly such
+    pixels (tools/diag_gates.py, profiles/r05_iid_worst_entries.json): |Z - D_p| / (Z + D_p) of 3e-4 .. 2e-3 with a
+    depth slope of tens per pixel, auto-mask comparisons decided by 1e-3 with colour slopes of 2 .. 4 per pixel."""
     assert tgt_img.dtype == torch.float64
     B, _, H, W = tgt_img.shape
     Kinv = inv3x3(K, "explicit")
@@ -388,11 +405,16 @@ def pairwise_gate_margins(tgt_img, ref_img, tgt_depth, ref_depth, pose, K, with_
     fx, fy = ix - ix.floor(), iy - iy.floor()
     own = inside & ((torch.minimum(fx, 1 - fx) < eps_px) | (torch.minimum(fy, 1 - fy) < eps_px))
     warped, valid, proj_depth, comp_depth = inverse_warp2(ref_img, tgt_depth, ref_depth, pose, K, padding_mode, "explicit")
+    # how far the sampled colours / depth move per pixel of sampling-position error (0 where nothing is sampled)
+    xs, ys, _ = project(back_project(tgt_depth.squeeze(1), Kinv), P[:, :, :3], P[:, :, 3:], padding_mode)
+    slope_img = _sampling_slopes(ref_img, xs, ys, padding_mode) * eps_slope_px       # [B,3,H,W]
+    slope_dep = _sampling_slopes(ref_depth, xs, ys, padding_mode)[:, 0] * eps_slope_px  # [B,H,W]
     d = tgt_img - warped
-    soft = ((d.abs() < eps_val) | ((d.abs() - 1).abs() < eps_val)).any(dim=1)
+    ev = eps_val + slope_img
+    soft = ((d.abs() < ev) | ((d.abs() - 1).abs() < ev)).any(dim=1)
     if with_auto_mask:
         ident = (tgt_img - ref_img).abs().mean(dim=1)
-        soft |= (d.abs().clamp(0, 1).mean(dim=1) - ident).abs() < eps_val
+        soft |= (d.abs().clamp(0, 1).mean(dim=1) - ident).abs() < eps_val + slope_img.mean(dim=1)
     if with_ssim:
         # (1 - SSIM)/2 before its clamp
         xp, yp = _reflect_pad1(tgt_img), _reflect_pad1(warped)
@@ -403,7 +425,9 @@ def pairwise_gate_margins(tgt_img, ref_img, tgt_depth, ref_depth, pose, K, with_
         soft |= ((raw.abs() < eps_val) | ((raw - 1).abs() < eps_val)).any(dim=1)
     dd = (comp_depth - proj_depth).abs() / (comp_depth + proj_depth)
     # (a pixel that samples nothing has projected depth 0 and diff_depth == 1 exactly, in any precision: no hazard)
-    soft |= ((dd < eps_val) | (((dd - 1).abs() < eps_val) & (proj_depth != 0))).squeeze(1)
+    # d dd / d D_p is at most 2 / (Z + D_p) in magnitude
+    edd = (eps_val + 2 * slope_dep / (comp_depth + proj_depth).squeeze(1)).unsqueeze(1)
+    soft |= ((dd < edd) | (((dd - 1).abs() < edd) & (proj_depth != 0))).squeeze(1)
     xa = ix.floor().clamp(0, W - 2).long()
     ya = iy.floor().clamp(0, H - 2).long()
     return {"hard": hard, "soft": soft, "own": own, "xa": xa, "ya": ya}

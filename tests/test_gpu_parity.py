@@ -31,7 +31,15 @@ POSE_RTOL_IID = 3e-2
 # statistic (which near-gate entry the margins just fail to set aside) -- measured in round 4 (gpurun_out/pytest_gpu_r04d.log
 # and the session after it): 0.8 .. 1.5x on image-like depth, 2.9x with border padding, 3.6 .. 6.6x on iid depth (5.8e-2
 # against 8.8e-3 of the scale).  Round 3 held these to the constants 3e-3 / 1e-1; the bounds are now relative to the run.
-ENTRYWISE_MAX_FACTOR = {"smooth": 4.0, "iid": 10.0, "scene": 4.0}
+ENTRYWISE_MAX_FACTOR = {"smooth": 4.0, "iid": 4.0, "scene": 4.0}
+# Round 5: the iid bound was 10 (measured 3.6 .. 6.6).  tools/diag_gates.py traced the 20 worst judged entries of every map
+# (profiles/r05_iid_worst_entries.json): all of them pixels whose VALUE gates -- sign / clamp of the depth inconsistency,
+# the auto-mask comparison -- were decided by 3e-4 .. 2e-3 while the sampled depth / colour changes by tens / by 2 .. 4 per
+# pixel of sampling position there, i.e. gates the margins' constant eps_val = 2e-4 did not set aside although a few ulp
+# of the coordinate flip them.  The margins now grow with the local slope of what is sampled
+# (oracle.pairwise_gate_margins: eps_slope_px); with them the same HIP gradients measure 1.2 / 2.0 / 1.2 x the reference
+# arithmetic's own worst entry on the three maps, and 81 .. 90 % of the iid entries are judged (91 .. 96 % elsewhere).
+ENTRYWISE_MIN_SHARE = {"smooth": 0.90, "iid": 0.78, "scene": 0.90}
 # test_iid_pose_gradients_as_row_statistics_over_seeds: HIP's row errors against the fp32 reference arithmetic's
 IID_ROW_FACTOR = 2.0
 FLAGS = [(1, 1, 1), (1, 1, 0), (1, 0, 1), (1, 0, 0), (0, 1, 1), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
@@ -734,7 +742,7 @@ def test_depth_gradients_entrywise_away_from_the_gates(LF, dev, B, depth, pad):
     fixed-point scatter window) -- judged entry by entry at BASELINE size, with NO outlier allowance.
 
     Every entry of the three depth gradients of compute_photo_and_geometry_loss whose value cannot hinge on a gate
-    decided within fp32 round-off (oracle.pairwise_gate_margins, evaluated in fp64; >= 92 % of the entries) must lie
+    decided within fp32 round-off (oracle.pairwise_gate_margins, evaluated in fp64; >= 90 % of the entries, 78 % on iid inputs) must lie
     within ENTRYWISE_MAX_FACTOR[depth] x the worst such entry of the reference's own fp32 arithmetic in the same run -- the entries set aside
     are off by up to a third of it, in the reference's own fp32 arithmetic as much as here (measured,
     tools/diag_gates.py) -- and the error distribution over those entries (median, 99 %, 99.9 %, 99.99 %) must be no wider than
@@ -772,7 +780,7 @@ def test_depth_gradients_entrywise_away_from_the_gates(LF, dev, B, depth, pad):
         print(f"[{depth}/{pad}] map {i}: judged {share:.4f} of the entries; error / scale: hip median {qh[0]:.2e} p99 {qh[1]:.2e} "
               f"p99.9 {qh[2]:.2e} p99.99 {qh[3]:.2e} max {float(eh.max()):.2e} | reference fp32 {qo[0]:.2e} {qo[1]:.2e} {qo[2]:.2e} {qo[3]:.2e} max {float(eo.max()):.2e} "
               f"| set aside: hip max {float(((a - c).abs() / scale)[u].max()):.2e}")
-        assert share >= 0.92, (i, share)
+        assert share >= ENTRYWISE_MIN_SHARE[depth], (i, share)
         # the worst judged entry: no further from fp64 than ENTRYWISE_MAX_FACTOR x the worst entry of the reference's own
         # fp32 arithmetic in this very run (round 3 used constants: 3e-3, and 1e-1 on iid inputs)
         assert float(eh.max()) <= ENTRYWISE_MAX_FACTOR[depth] * float(eo.max()) + 1e-6, (i, float(eh.max()), float(eo.max()))
