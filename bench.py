@@ -188,6 +188,9 @@ def e2e_train(args, device, world, dev_index, barrier, dist_on=False):
         hip_dist.enable_exact_normalisation()
     disp_net = models.DispResNet(args.resnet_layers, False).to(device).train()
     pose_net = models.PoseResNet(18, False).to(device).train()
+    targs.channels_last = int(getattr(args, "channels_last", 0))
+    if targs.channels_last:
+        disp_net, pose_net = disp_net.to(memory_format=torch.channels_last), pose_net.to(memory_format=torch.channels_last)
     n_grad = 0
     if dist_on:
         T.freeze_unused_scale_heads(disp_net, targs.num_scales)
@@ -344,6 +347,9 @@ def main():
     ap.add_argument("--force-dist", default="none", choices=["none", "nccl", "gloo"],
                     help="with one rank: still create a process group of this backend, wrap the nets in "
                          "DistributedDataParallel and run every collective of the multi-GPU path (world size 1)")
+    ap.add_argument("--channels-last", type=int, default=0,
+                    help="1: the nets of the training-step leg in NHWC memory format (train.py --channels-last); the "
+                         "line then says so in config.memory_format and is NOT the headline configuration")
     ap.add_argument("--exact", type=int, default=0, help="1: exact mask normalisation (scsfm_hip.dist: one all-reduce of "
                                                          "the pairs' raw sums per step) in the distributed legs")
     args = ap.parse_args()
@@ -554,7 +560,8 @@ def main():
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": parallelism},
+            "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": parallelism,
+                       "memory_format": "channels_last (nets only; --channels-last 1, not the default)" if args.channels_last else "contiguous (NCHW)"},
             # ranks an all-reduce on the process group actually spanned: `rccl_ranks` only when that group is nccl (= RCCL)
             ("rccl_ranks" if backend in (None, "nccl") else "collective_ranks"): e2e["ranks"] if e2e is not None else world,
             "collective_backend": backend,

@@ -668,7 +668,7 @@ __device__ __forceinline__ void atomic_add_at(T* __restrict__ base, unsigned byt
 template <typename T, typename Cell, int WW, int WH, int NT = kThreads>
 __device__ __forceinline__ void flush_scatter_region(const Cell (*win)[WW], int wx0, int wy0, int cx0,
                                                      int cy0, int cx1, int cy1, T* __restrict__ gplane, int W,
-                                                     const WideWin& ww = WideWin{WH, 0, 0}, T unit = T(1)) {
+                                                     const WideWin& ww = WideWin{WH, 0, 0}) {
   cx0 = cx0 < 0 ? 0 : cx0; cy0 = cy0 < 0 ? 0 : cy0;
   cx1 = cx1 > WW - 1 ? WW - 1 : cx1; cy1 = cy1 > ww.rows - 1 ? ww.rows - 1 : cy1;
   const int w = cx1 - cx0 + 1, h = cy1 - cy0 + 1;
@@ -692,8 +692,8 @@ __device__ __forceinline__ void flush_scatter_region(const Cell (*win)[WW], int 
     const bool second = i + NT < n;
     const Cell v0 = (&win[0][0])[cell_of(ry, rx)];
     const Cell v1 = second ? (&win[0][0])[cell_of(ry2, rx2)] : Cell(0);
-    if (v0 != Cell(0)) atomic_add_at(gplane, dest_of(ry, rx), T(win_value(v0)) * unit);
-    if (v1 != Cell(0)) atomic_add_at(gplane, dest_of(ry2, rx2), T(win_value(v1)) * unit);
+    if (v0 != Cell(0)) atomic_add_at(gplane, dest_of(ry, rx), T(win_value(v0)));
+    if (v1 != Cell(0)) atomic_add_at(gplane, dest_of(ry2, rx2), T(win_value(v1)));
     ry = ry2 + dq; rx = rx2 + dr;
     if (rx >= w) { rx -= w; ++ry; }
   }
@@ -702,7 +702,7 @@ __device__ __forceinline__ void flush_scatter_region(const Cell (*win)[WW], int 
     const int ry = int((float(i) + 0.5f) * iw);  // i / w, exact for the few thousand cells of a window
     const int ly = cy0 + ry, lx = cx0 + (i - ry * w);
     const Cell v = (&win[0][0])[ly * WW + lx + (ww.rows > WH ? wide_adjust<WH>(ww, ly) : 0)];
-    if (v != Cell(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), T(win_value(v)) * unit);
+    if (v != Cell(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), T(win_value(v)));
   }
 #endif
 }

@@ -424,22 +424,6 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) 
   if (hint) r_hint = hint[0] != 0.0 ? T(3.0 * hint[1] / hint[0]) : T(0);  // (scsfm_pair_desc::hint: the device's pair wins)
   spec_tile<T, kSsim, kScaled, kFlags, kStageFwd>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, pb, B, H, W, flags, nullptr, nullptr, r_hint);
 }
-// The re-speculation pass of the backward (scsfm_spec_tile.h: kRespec): a persistent grid that walks the tiles, so that
-// the usual case -- every pair's speculation holds -- costs one look at the pairs' sums per workgroup.
-template <typename T, bool kSsim, bool kScaled>
-__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 3 : 1) void pair_respec_kernel(
-    PairBatch<T> pb, int nbx, int nby, int nz, int B, int H, int W, unsigned flags, const T* __restrict__ g_photo,
-    const T* __restrict__ g_geom) {
-  const unsigned live = pairs_to_run(pb, nz / B, g_photo, g_geom);
-  if (!live) return;
-  const int n = nbx * nby * nz;
-  for (int t = blockIdx.x; t < n; t += gridDim.x) {
-    const BlockId blk = xcd_tile_of(t, nbx, nby, nz);
-    if (!((live >> (blk.z / B)) & 1u)) continue;
-    spec_tile<T, kSsim, kScaled, kRuntimeFlags, false, true>(blk, nbx, nby, pb, B, H, W, flags, g_photo, g_geom, T(0));
-    __syncthreads();  // the tile's LDS is reused
-  }
-}
 #ifdef SCSFM_WITH_MARCH
 #ifndef SCSFM_MARCH_WAVES_PER_SIMD  // waves per SIMD the march is compiled for (168 VGPRs at 3: no spills; 128 at 4: spills)
 #define SCSFM_MARCH_WAVES_PER_SIMD 3
@@ -1131,25 +1115,6 @@ __global__ __launch_bounds__(kThreads) void pairs_zero_prep_kernel(PairBatch<T> 
   for (size_t i = nq * Q + t0; i < n; i += stride) p[i] = T(0);
 }
 
-// In front of pair_respec_kernel: the clear of the scatter planes it accumulates into (the forward's speculative scatter is
-// in them): only the planes of pairs that will be recomputed.
-template <typename T>
-__global__ __launch_bounds__(kThreads) void pairs_respec_clear_kernel(PairBatch<T> pb, size_t n, int npairs,
-                                                                      const T* __restrict__ g_photo,
-                                                                      const T* __restrict__ g_geom) {
-  const unsigned live = pairs_to_run(pb, npairs, g_photo, g_geom);
-  if (!((live >> blockIdx.y) & 1u)) return;
-  T* __restrict__ p = pb.p[blockIdx.y].gbuf + kPlaneScatter * n;
-  constexpr int Q = 16 / sizeof(T);
-  const size_t stride = (size_t)gridDim.x * kThreads, t0 = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  const size_t nq = (reinterpret_cast<size_t>(p) & 15) == 0 ? n / Q : 0;
-  Quad<T> z;
-#pragma unroll
-  for (int j = 0; j < Q; ++j) z.v[j] = T(0);
-  for (size_t i = t0; i < nq; i += stride) reinterpret_cast<Quad<T>*>(p)[i] = z;
-  for (size_t i = nq * Q + t0; i < n; i += stride) p[i] = T(0);
-}
-
 // ------------------------------------------------------------------------------------------
 // Host side of the C ABI.
 // ------------------------------------------------------------------------------------------
@@ -1207,10 +1172,6 @@ static unsigned debug_extra_lds() {
 // Which kernel serves the speculative forward: the tile kernel, or -- in builds that carry them -- the column march
 // (SCSFM_SPEC_KERNEL=march) or the tile kernel with LDS-staged forward taps (SCSFM_SPEC_KERNEL=stagefwd); for A/B
 // measurements and the CPU simulation, read per launch.
-static bool respec_enabled() {
-  const char* e = getenv("SCSFM_RESPEC");
-  return !(e && e[0] == '0');
-}
 static bool spec_uses_march() {
 #ifdef SCSFM_WITH_MARCH
   const char* e = getenv("SCSFM_SPEC_KERNEL");
@@ -1379,28 +1340,8 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
       full_res = full_res && d[i0 + i].depth_shift == 0;
     }
     const int nax = ceil_div(W, kTileW - 2), nay = ceil_div(H, Tile<T>::kH - 2);
-    int nbx = ceil_div(W, kWave), nby = ceil_div(H, kGeomRows * (kThreads / kWave));
-    // Workspaces a speculative forward left (every pair of the chunk has its gbuf behind its workspace): a failed
-    // speculation is repaired by running the forward's own tile again with the true coefficients (one pass: ~300 us
-    // at configs[1]) instead of the two separate passes (283 + 219 us); the guard at the top of either costs the same
-    // when the speculation holds.  SCSFM_RESPEC=0 (read per call): the two passes, for A/B measurements.
-    bool respec = !(flags & (SCSFM_DEBUG_SKIP_PHOTO | SCSFM_DEBUG_SKIP_GEOM)) && respec_enabled();
-    for (int i = 0; i < m; ++i) respec = respec && d[i0 + i].gbuf != nullptr;
-    if (respec) {
-      hipLaunchKernelGGL((pairs_respec_clear_kernel<T>), dim3(256, m), dim3(kThreads), 0, stream, pb, npx, m, g_photo, g_geom);
-      const int g = nax * nay * m * B < kPersistentGrid ? nax * nay * m * B : kPersistentGrid;
-#define SCSFM_LAUNCH_RESPEC(SSIM, SCALED)                                                                               \
-  hipLaunchKernelGGL((pair_respec_kernel<T, SSIM, SCALED>), dim3(g), dim3(kThreads), 0, stream, pb, nax, nay, m * B, B, H, W, \
-                     flags, g_photo, g_geom)
-      if (flags & SCSFM_WITH_SSIM) {
-        if (full_res) SCSFM_LAUNCH_RESPEC(true, false); else SCSFM_LAUNCH_RESPEC(true, true);
-      } else {
-        if (full_res) SCSFM_LAUNCH_RESPEC(false, false); else SCSFM_LAUNCH_RESPEC(false, true);
-      }
-#undef SCSFM_LAUNCH_RESPEC
-      nbx = nax; nby = nay;  // the pose partials are per tile of THIS grid (what the reducer below is told)
-    }
-    if (!respec && !(flags & SCSFM_DEBUG_SKIP_PHOTO)) {
+    const int nbx = ceil_div(W, kWave), nby = ceil_div(H, kGeomRows * (kThreads / kWave));
+    if (!(flags & SCSFM_DEBUG_SKIP_PHOTO)) {
       const int g = nax * nay * m * B < kPersistentGrid ? nax * nay * m * B : kPersistentGrid;
 #define SCSFM_LAUNCH_PHOTO(SSIM, SCALED)                                                                                   \
   hipLaunchKernelGGL((pair_bwd_photo_kernel<T, SSIM, SCALED>), dim3(g), dim3(kThreads), 0, stream, pb, nax, nay, m * B, B, H, \
@@ -1412,7 +1353,7 @@ static int pairs_bwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
       }
 #undef SCSFM_LAUNCH_PHOTO
     }
-    if (!respec && !(flags & SCSFM_DEBUG_SKIP_GEOM)) {
+    if (!(flags & SCSFM_DEBUG_SKIP_GEOM)) {
       const int g = nbx * nby * m * B < kPersistentGrid ? nbx * nby * m * B : kPersistentGrid;
       if (full_res)
         hipLaunchKernelGGL((pair_bwd_geom_kernel<T, false>), dim3(g), dim3(kThreads), 0, stream, pb, nbx, nby, m * B, B, H, W,

@@ -30,13 +30,7 @@ __device__ __forceinline__ void sched_fence() {
 #define SCSFM_STAGE_TAPS 1
 #endif
 
-// kRespec (the backward of a step whose upstream gradients do not stand in the ratio the forward speculated on -- once
-// per change of the loss weights): the same tile with the TRUE coefficients a = g_photo / (3 S_m), b = g_geom / S_m read
-// from the device; tiles of pairs whose speculation holds return at once.  The planes and pose partials it leaves are
-// final (the combine applies no factor: retire_speculation), the forward's three sums are not written again, and the
-// scatter window counts in units of max(|a|, |b|) (the values carry the 1e-5-sized factor).  Replaces the two separate
-// passes (photo_tile + geom_tile: 283 + 219 us at configs[1]) for workspaces a speculative forward left.
-template <typename T, bool kSsim, bool kScaled, unsigned kFlags, bool kStageFwd = false, bool kRespec = false>
+template <typename T, bool kSsim, bool kScaled, unsigned kFlags, bool kStageFwd = false>
 // (kSpec: always true here -- the backward's own tiled pass is photo_tile in scsfm_pair.hip)
 __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, const PairBatch<T>& pb, int B, int H,
                                            int W, unsigned flags_arg, const T* __restrict__ g_photo,
@@ -75,19 +69,6 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
 
   // upstream gradient x d(masked mean)/d(sum): zero when the 10000-pixel gate was closed
   T a = T(1), bg = r_hint;
-  T win_unit_v = T(1), win_inv_unit = T(1);  // (constants 1 unless kRespec)
-  if constexpr (kRespec) {
-    a = T(sums[5]) * g_photo[0];
-    bg = T(sums[6]) * g_geom[0];
-    if (a == T(0) && bg == T(0)) return;            // workgroup-uniform
-    if (spec_valid(sums, g_photo, g_geom)) return;  // the forward's planes stand
-    if (sizeof(T) == 4) {  // the unit of the fixed-point cells: as in geom_tile (scsfm_pair.hip)
-      const T ca = t_abs(a), cb_ = t_abs(bg);
-      const T want = (flags & SCSFM_WITH_MASK) ? (ca > cb_ ? ca : cb_) : cb_;
-      win_unit_v = want > T(1.17549435e-38f) ? want : T(1.17549435e-38f);
-      win_inv_unit = T(1) / win_unit_v;
-    }
-  }
   if constexpr (!kSpec) {
     a = T(sums[5]) * g_photo[0];
     bg = T(sums[6]) * g_geom[0];
@@ -403,8 +384,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     }
     STAMP(4);
     // (contains a barrier: the window's zeroes are visible below even without SSIM)
-    if constexpr (kRespec) __syncthreads();  // (the forward's sums were reduced long ago: nothing to store)
-    else block_sum_store<3>(v, red, partials + 3 * ((size_t)(b * nby + blk.y) * nbx + blk.x));
+    block_sum_store<3>(v, red, partials + 3 * ((size_t)(b * nby + blk.y) * nbx + blk.x));
     STAMP(5);
     // ---- geometry tail: pass B for the owned pixels, up to the factor the reduction will supply ----
     // (everything downstream of dL/d(warped colour), dL/d diff_depth is linear in them: the dense plane, the
@@ -478,10 +458,10 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
       if constexpr (kStage) {
         const GeomTaps<T> f = geom_fetch<kStageRows, !kLean>(bc, px, py, d_own[k], refP, ref_depth, H, W, flags, staged);
         gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, d_own[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc, ww,
-                                              win_inv_unit, ovf);
+                                              T(1), ovf);
       } else {
         gd[k] = geom_pixel<T, Cell, WW, WH>(bc, px, py, d_own[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
-                                      wy0, g_scatter, acc, win_inv_unit, ovf);
+                                      wy0, g_scatter, acc, T(1), ovf);
       }
     }
     // A barrier waits for every outstanding global store / atomic of the wave, so everything that writes to
@@ -499,7 +479,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
         st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gd[k]);
     }
     if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5)))
-      flush_scatter_region<T, Cell, WW, WH>(win, wx0, wy0, cx0, cy0, cx1, cy1, g_scatter, W, ww, win_unit_v);
+      flush_scatter_region<T, Cell, WW, WH>(win, wx0, wy0, cx0, cy0, cx1, cy1, g_scatter, W, ww);
     STAMP(8);
   }
 }

@@ -85,6 +85,10 @@ parser.add_argument('--gpu-augment', action='store_true',
 parser.add_argument('--single-loss-node', type=int, default=1,
                     help='1: the two losses and their weighted sum behind one autograd node (extension; same values and '
                          'gradients, fewer launches), 0: the three reference-style calls')
+parser.add_argument('--channels-last', type=int, default=0,
+                    help='1: both nets (weights and activations) in NHWC memory format -- MIOpen\'s fp32 igemm solvers then need '
+                         'no NCHW<->NHWC transposes around them; the loss path keeps reading the NCHW batch.  Off by default: '
+                         'other solvers, other rounding (losses equal to ~1e-6, not bit for bit)')
 parser.add_argument('--exact-mask-normalisation', action='store_true',
                     help='data parallel: all-reduce the mask sums so the loss equals the single-process loss on the global batch. '
                          '(BatchNorm running statistics stay per rank either way -- as per replica under the reference\'s '
@@ -203,6 +207,8 @@ def main():
         print("=> creating model")
     disp_net = models.DispResNet(args.resnet_layers, args.with_pretrain).to(device)
     pose_net = models.PoseResNet(18, args.with_pretrain).to(device)
+    if args.channels_last:
+        disp_net, pose_net = disp_net.to(memory_format=torch.channels_last), pose_net.to(memory_format=torch.channels_last)
     if args.pretrained_disp:
         if is_main:
             print("=> using pre-trained weights for DispResNet")
@@ -310,8 +316,13 @@ def train_step(args, disp_net, pose_net, optimizer, tgt_img, ref_imgs, intrinsic
     The returned ``loss`` is the unscaled w1*l1 + w2*l2 + w3*l3."""
     w1, w2, w3 = args.photo_loss_weight, args.smooth_loss_weight, args.geometry_consistency_weight
     scale = getattr(args, 'world', 1) if getattr(args, 'exact_mask_normalisation', False) else 1
-    tgt_depth, ref_depths = compute_depth(disp_net, tgt_img, ref_imgs)
-    poses, poses_inv = compute_pose_with_inv(pose_net, tgt_img, ref_imgs)
+    if getattr(args, 'channels_last', 0):  # the nets read NHWC copies; the loss path below keeps the NCHW batch
+        net_tgt = tgt_img.contiguous(memory_format=torch.channels_last)
+        net_refs = [r.contiguous(memory_format=torch.channels_last) for r in ref_imgs]
+    else:
+        net_tgt, net_refs = tgt_img, ref_imgs
+    tgt_depth, ref_depths = compute_depth(disp_net, net_tgt, net_refs)
+    poses, poses_inv = compute_pose_with_inv(pose_net, net_tgt, net_refs)
     if getattr(args, 'single_loss_node', 1) and compute_total_loss is not None:
         # the three lines of the reference below as one autograd node (same values and gradients, fewer launches)
         objective, loss_1, loss_2, loss_3 = compute_total_loss(tgt_img, ref_imgs, intrinsics, tgt_depth, ref_depths, poses,
