@@ -443,6 +443,35 @@ def test_compressive_warps_do_not_wrap_the_fixed_point_window(dev, B, scale, tz,
         assert _rel64(g_td[0].double(), td64[0].grad) < 1e-4, check
 
 
+@pytest.mark.parametrize("depth", ["smooth", "iid", "scene"])
+def test_no_window_cell_wraps_on_the_bench_inputs(LF, dev, depth, monkeypatch):
+    """The exact wrap detector (SCSFM_CHECK_WINDOW=1: returning LDS atomics in the speculative forward and in the fallback
+    geometry pass) on the bench's own batches at configs[1] size, through the autograd nodes: no fixed-point cell of any
+    of the 12,768 tiles wraps -- with the hinted weights (speculation holds) and with other weights (fallback passes) --,
+    and the debug launch's losses equal the product launch's."""
+    from scsfm_hip import capi, synth
+    d = synth.make_batch(12, 256, 832, n_ref=2, seed=0, depth=depth, image=synth.image_law(depth), dataset="kitti")
+    to = lambda t: t.to(dev)
+    tgt, K, refs = to(d["tgt_img"]), to(d["intrinsics"]), [to(t) for t in d["ref_imgs"]]
+
+    def step(w_geom):
+        mv = lambda t: t.to(dev).clone().requires_grad_(True)
+        td, rd = [mv(d["tgt_depth"][0])], [[mv(r[0])] for r in d["ref_depths"]]
+        ps, pi = [mv(p) for p in d["poses"]], [mv(p) for p in d["poses_inv"]]
+        photo, geom = LF.compute_photo_and_geometry_loss(tgt, refs, K, td, rd, ps, pi, 1, 1, 1, 1, "zeros")
+        (photo + w_geom * geom).backward()  # (raises capi.WindowOverflow under SCSFM_CHECK_WINDOW=1 if a cell wrapped)
+        return float(photo.detach()), float(geom.detach()), td[0].grad.clone()
+
+    plain = step(0.5)
+    monkeypatch.setenv("SCSFM_CHECK_WINDOW", "1")
+    checked = step(0.5)     # speculation holds: the forward's tail is what scatters
+    step(0.3)               # other weights: the fallback passes scatter
+    monkeypatch.delenv("SCSFM_CHECK_WINDOW")
+    assert plain[0] == checked[0] and plain[1] == checked[1]
+    scale = float(plain[2].abs().max())
+    assert float((plain[2] - checked[2]).abs().max()) <= 1e-5 * scale  # (direct atomics of a tile add in another order)
+
+
 def test_boundary_functions(IW, dev):
     """pixel2cam / cam2pixel / cam2pixel2 / legacy inverse_warp (euler and quat) on the hardware, fp64 and fp32,
     values and gradients against the oracle (tests/_boundary_checks.py; CPU twin: tests/test_boundary_names.py)."""
