@@ -1,4 +1,4 @@
-"""The column-march variant of the speculative forward (variants/src/scsfm_march.h; DESIGN.md 3a: measured slower than the tile
+"""The column-march variant of the speculative forward (variants/src/scsfm_march.h; profiles/HISTORY.md 3a: measured slower than the tile
 kernel, compiled only with -DSCSFM_WITH_MARCH, which the host-simulation build defines) stays parity-green: the
 speculative-forward checks of test_hostsim_kernels.py re-run with SCSFM_SPEC_KERNEL=march (read per launch), at a
 segment height that is no multiple of the chunk's, so that first / last chunks and carried rows are all exercised."""

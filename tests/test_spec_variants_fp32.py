@@ -1,7 +1,7 @@
 """The fp32 speculative forward -- the kernel that ships: 40 KB of aliased LDS (kLean), the tail's LDS-staged taps
 (kStage), the fixed-point scatter window -- in the CPU simulation, against the fp64 oracle; and its variant with the
 FORWARD warp's taps staged in LDS as well (variants/src/scsfm_spec_stagefwd.inc, kStageFwd; SCSFM_SPEC_KERNEL=stagefwd in builds
-with -DSCSFM_WITH_MARCH, which the simulation's build defines; DESIGN.md 3a: measured 2.4 % slower, not the
+with -DSCSFM_WITH_MARCH, which the simulation's build defines; profiles/HISTORY.md 3a: measured 2.4 % slower, not the
 product) against both the oracle and the product kernel: the two evaluate the same arithmetic on the same texels, so
 the forward sums and the pose gradients must agree bit for bit; only the placement of the scatter window differs
 (fixed-point cells vs fp32 atomics for some taps), which shows in the last bits of the depth gradients."""
