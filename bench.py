@@ -347,6 +347,9 @@ def main():
     ap.add_argument("--force-dist", default="none", choices=["none", "nccl", "gloo"],
                     help="with one rank: still create a process group of this backend, wrap the nets in "
                          "DistributedDataParallel and run every collective of the multi-GPU path (world size 1)")
+    ap.add_argument("--other-laws", type=int, default=1,
+                    help="1: after the headline legs also time the dominant kernel inside a few eager steps on the scene and iid "
+                         "depth laws (1-GPU runs of the smooth law only; `roofline_other_depth_laws`)")
     ap.add_argument("--channels-last", type=int, default=0,
                     help="1: the nets of the training-step leg in NHWC memory format (train.py --channels-last); the "
                          "line then says so in config.memory_format and is NOT the headline configuration")
@@ -527,6 +530,33 @@ def main():
                 "algorithmic_bytes_per_launch": spec_bytes, "avg_launch_us": round(launch_s * 1e6, 2),
                 "launches_timed": in_step_us[2], "min_launch_us": round(in_step_us[1], 2),
                 "back_to_back_launch_us": round(kt["spec_kernel_only"] * 1e6, 2)}
+    # the same kernel inside eager steps on the OTHER synthetic depth laws (rank 0 of a 1-GPU run of the headline law only):
+    # `scene` = piecewise-smooth depth with occlusion edges, the closest stand-in for a trained net's output; `iid` =
+    # the incoherent stress case.  Same algorithmic bytes, same 8 TB/s.
+    other_laws = {}
+    if args.other_laws and world == 1 and args.depth == "smooth":
+        import argparse as _ap
+        for law in ("scene", "iid"):
+            a2 = _ap.Namespace(**vars(args))
+            a2.depth = law
+            x2, _ = make_inputs(a2, seed=rank, device=device)
+            for _ in range(3):
+                hot_path_step(LF, x2, flags)
+            torch.cuda.synchronize()
+            n2 = max(5, min(20, args.loss_steps))
+            lib.call("scsfm_profile_begin", n2)
+            t0 = time.perf_counter()
+            for _ in range(n2):
+                hot_path_step(LF, x2, flags)
+            torch.cuda.synchronize()
+            step_ms = (time.perf_counter() - t0) / n2 * 1e3
+            lib.call("scsfm_profile_end", ctypes.addressof(prof_mean), ctypes.addressof(prof_min), ctypes.addressof(prof_n))
+            if prof_n.value > 0:
+                other_laws[law] = {"avg_launch_us": round(prof_mean.value, 2), "min_launch_us": round(prof_min.value, 2),
+                                   "launches_timed": prof_n.value,
+                                   "frac": round(spec_bytes / (prof_mean.value * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "eager_loss_path_ms_per_step": round(step_ms, 4)}
+            del x2
     # SURVEY.md 8d figure: one pair-direction forward + backward = 48 B/px
     pair_t = (kt["pairs_fwd_spec"] + kt["pairs_bwd_after_spec"]) / n_pairs
     pair_roofline = {"algorithmic_bytes": 48 * n_px, "us": round(pair_t * 1e6, 2),
@@ -583,6 +613,8 @@ def main():
                           "losses": {"total": loss, "photo": photo, "smooth": smooth, "geometry": geom},
                           "pair_direction_roofline": pair_roofline},
             "roofline": roofline,
+            # the dominant kernel on the other two depth laws (same bytes, same peak; --other-laws 0 skips the leg)
+            "roofline_other_depth_laws": other_laws or None,
             "library": ident,
         }
         if world == 1 and args.cpu_seconds > 0:
