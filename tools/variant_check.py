@@ -29,9 +29,23 @@ def main():
     lib = _lib.get()
     dev = torch.device("cuda:0")
     out = {"lib": os.path.basename(lib.path), "us": {}, "check": {}}
+    # -DSCSFM_RGBD builds (round 6) read the reference frames through [B, H, W, 4] texel planes registered here
+    register = getattr(lib._dll, "scsfm_debug_register_texels", None) if hasattr(lib._dll, "scsfm_debug_register_texels") else None
+    keep = []
     for depth in a.depths.split(","):
         a.depth = depth
         x, _ = bench.make_inputs(a, 0, dev)
+        if register is not None:
+            import ctypes
+            register.argtypes = [ctypes.c_void_p] * 3
+            register(None, None, None)
+            frames = [(x["tgt_img"], x["tgt_depth"][0])] + [(i, r[0]) for i, r in zip(x["ref_imgs"], x["ref_depths"])]
+            pack = lambda: [torch.cat([i, d.detach()], 1).permute(0, 2, 3, 1).contiguous() for i, d in frames]
+            tex = pack()
+            keep.append(tex)
+            for (i, d), t in zip(frames, tex):
+                assert register(i.data_ptr(), d.data_ptr(), t.data_ptr()) == 0
+            out.setdefault("us_pack_torch", {})[depth] = round(bench._event_time(pack, 10) * 1e6, 1)
         loss, photo, smooth, geom = bench.hot_path_step(LF, x, (1, 1, 1, "zeros"))
         gs = [x["tgt_depth"][0].grad] + [r[0].grad for r in x["ref_depths"]]
         ps = x["poses"] + x["poses_inv"]
@@ -46,6 +60,19 @@ def main():
         _, _, _, ws = capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, pp, pis, hint=(1.0, 0.5))
         fn = lambda: capi.photo_geometry_fwd(lib, fl | 16384, tgt, K, refs, tds, rds, pp, pis, hint=(1.0, 0.5), ws=ws)
         out["us"][depth] = [round(bench._event_time(fn, a.iters) * 1e6, 1) for _ in range(a.rounds)]
+        if a.extra or register is not None:
+            # the smooth loss's forward over the step's frames; with texel planes registered it packs them on the way
+            sm_frames, sm_imgs = tds + [r[0] for r in rds], [tgt] + list(refs)
+            sm = lambda: capi.smooth_multi_fwd(lib, sm_frames, sm_imgs)
+            out.setdefault("us_smooth_fwd", {})[depth] = [round(bench._event_time(sm, a.iters) * 1e6, 1) for _ in range(a.rounds)]
+            if register is not None:
+                for t_ in keep[-1]:
+                    t_.fill_(float("nan"))
+                sm()
+                ref_tex = pack()
+                out.setdefault("pack_matches", {})[depth] = bool(all(torch.equal(p_, q_) for p_, q_ in zip(keep[-1], ref_tex)))
+                register(None, None, None)
+                out.setdefault("us_smooth_fwd_no_pack", {})[depth] = [round(bench._event_time(sm, a.iters) * 1e6, 1) for _ in range(a.rounds)]
         if a.extra:
             # the plain forward (validation path: prep + pair_fwd_kernel + finalize) and the backward of the first step
             # after a weight change (guards fail: pair_bwd_photo + pair_bwd_geom + combine)
