@@ -417,67 +417,6 @@ __device__ __forceinline__ TapRows<T> load_tap_rows(const Planes3<T>& q, int c, 
   return r;
 }
 
-#ifndef SCSFM_RGBD  // experiment of round 6 (tuning builds): reference frames as [B, H, W, 4] texels (r, g, b, depth)
-#define SCSFM_RGBD 0
-#endif
-#if SCSFM_RGBD
-// One image of the batch as interleaved texels: a 2 x 2 block is four 16-byte gathers (two per row, the second an
-// immediate offset away) instead of the eight 8-byte gathers of four planes.
-template <typename T>
-struct Texel { T r, g, b, d; };
-template <typename T>
-struct TexelBlock { Texel<T> na, nb, sa, sb; };
-template <typename T>
-struct TexPlane {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __amdgpu_buffer_rsrc_t r;
-#else
-  const Texel<T>* p;
-#endif
-};
-template <typename T>
-__device__ __forceinline__ TexPlane<T> tex_plane(const T* __restrict__ base) {
-  TexPlane<T> q;
-#if defined(__HIP_DEVICE_COMPILE__)
-  q.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, 0xffffffffu, 0x00020000);
-#else
-  q.p = reinterpret_cast<const Texel<T>*>(base);
-#endif
-  return q;
-}
-// texel at ELEMENT offset `e` (pixels) of the image
-template <typename T>
-__device__ __forceinline__ Texel<T> ld_texel(const TexPlane<T>& q, unsigned e) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  static_assert(sizeof(T) == 4, "texel planes are an fp32 experiment");
-  return __builtin_bit_cast(Texel<T>, __builtin_amdgcn_raw_buffer_load_b128(q.r, e * 16u, 0, 0));
-#else
-  return q.p[e];
-#endif
-}
-template <typename T>
-__device__ __forceinline__ TexelBlock<T> load_texel_block(const TexPlane<T>& q, const Sample<T>& s) {
-  TexelBlock<T> t;
-#if defined(__HIP_DEVICE_COMPILE__)
-  t.na = __builtin_bit_cast(Texel<T>, __builtin_amdgcn_raw_buffer_load_b128(q.r, s.offr[0] * 16u, 0, 0));
-  t.nb = __builtin_bit_cast(Texel<T>, __builtin_amdgcn_raw_buffer_load_b128(q.r, s.offr[0] * 16u + 16u, 0, 0));
-  t.sa = __builtin_bit_cast(Texel<T>, __builtin_amdgcn_raw_buffer_load_b128(q.r, s.offr[1] * 16u, 0, 0));
-  t.sb = __builtin_bit_cast(Texel<T>, __builtin_amdgcn_raw_buffer_load_b128(q.r, s.offr[1] * 16u + 16u, 0, 0));
-#else
-  t.na = q.p[s.offr[0]]; t.nb = q.p[s.offr[0] + 1]; t.sa = q.p[s.offr[1]]; t.sb = q.p[s.offr[1] + 1];
-#endif
-  return t;
-}
-// the block as the four planes' tap rows (what bilerp_rows / geom_consume take)
-template <typename T>
-__device__ __forceinline__ void texel_rows(const TexelBlock<T>& t, TapRows<T> (&tc)[3], TapRows<T>& td) {
-  tc[0].n.a = t.na.r; tc[0].n.b = t.nb.r; tc[0].s.a = t.sa.r; tc[0].s.b = t.sb.r;
-  tc[1].n.a = t.na.g; tc[1].n.b = t.nb.g; tc[1].s.a = t.sa.g; tc[1].s.b = t.sb.g;
-  tc[2].n.a = t.na.b; tc[2].n.b = t.nb.b; tc[2].s.a = t.sa.b; tc[2].s.b = t.sb.b;
-  td.n.a = t.na.d; td.n.b = t.nb.d; td.s.a = t.sa.d; td.s.b = t.sb.d;
-}
-#endif
-
 // A depth map as the pair kernels read it.  Full resolution: the [H, W] plane.  kScaled (kernels instantiated for
 // multi-scale steps): the map of a coarser scale, [H >> ds, W >> ds], whose nearest up-sampling to (H, W)
 // (loss_functions.py:77-82: F.interpolate(..., mode='nearest') of every scale before compute_pairwise_loss) is

@@ -40,10 +40,6 @@ struct PairArgs {
   BatchConsts<T>* consts; double* sums; double* partials; double* gPp;
   T* out; T* gbuf; T* g_ref_depth; T* g_pose;
   int ds;  // log2 of the down-scale of BOTH depth maps of this pair (scsfm_pair_desc::depth_shift)
-#if SCSFM_RGBD
-  const T* ref_tex;  // the reference frame as [B, H, W, 4] texels (r, g, b, depth): scsfm_debug_register_texels
-  const T* tgt_tex;  // ... and the target frame
-#endif
 };
 constexpr int kMaxPairs = 8;
 // Planes of a pair's gbuf (each B x H x W): what the tiled pass hands to the geometry pass, and the geometry
@@ -1136,18 +1132,6 @@ static void profile_release() {
   g_profile = ProfileState();
 }
 
-#if SCSFM_RGBD
-// Experiment builds: the texel plane of a (colour image, depth map) pair of device pointers, registered by the harness
-// (tools/rgbd_check.py) -- no ABI change for a measurement.
-struct TexelEntry { const void* img; const void* depth; const void* tex; };
-static TexelEntry g_texels[32];
-static int g_ntexels = 0;
-const void* texels_of(const void* img, const void* depth) {
-  for (int i = 0; i < g_ntexels; ++i)
-    if (g_texels[i].img == img && g_texels[i].depth == depth) return g_texels[i].tex;
-  return nullptr;
-}
-#endif
 template <typename T>
 static PairArgs<T> make_pair_args(const scsfm_pair_desc& d, int B, int H, int W, void* shared_scratch, int idx) {
   const PairWs l = pair_ws_layout(B, H, W);
@@ -1166,10 +1150,6 @@ static PairArgs<T> make_pair_args(const scsfm_pair_desc& d, int B, int H, int W,
   a.g_ref_depth = (T*)d.g_ref_depth;
   a.g_pose = (T*)d.g_pose;
   a.ds = d.depth_shift;
-#if SCSFM_RGBD
-  a.ref_tex = (const T*)texels_of(d.ref_img, d.ref_depth);
-  a.tgt_tex = (const T*)texels_of(d.tgt_img, d.tgt_depth);
-#endif
   return a;
 }
 
@@ -1241,11 +1221,6 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
     if (!kernel_only)
       hipLaunchKernelGGL((pairs_zero_prep_kernel<T>), dim3(1024 + 1, n), dim3(kThreads), 0, stream, pb, npx, n, B, K);
     const T r_hint = w_photo != 0.0 ? T(3.0 * w_geom / w_photo) : T(0);
-#if SCSFM_RGBD
-    if (sizeof(T) == 4 && full_res && (flags & SCSFM_WITH_SSIM))
-      for (int i = 0; i < n; ++i)
-        if (!pb.p[i].ref_tex || !pb.p[i].tgt_tex) return SCSFM_ERR_ARG;  // (loudly: this build reads the reference frames through texels only)
-#endif
     const bool timed = g_profile.used < g_profile.n;
     if (timed) (void)hipEventRecord(g_profile.start[g_profile.used], stream);
     if (!spec_uses_march()) {
@@ -1613,16 +1588,6 @@ size_t scsfm_pair_ws_bytes(int B, int H, int W) {
     return scsfm::pair_refinalize<T>(B, H, W, ws, out, stream);                                                       \
   }
 
-#if SCSFM_RGBD
-int scsfm_debug_register_texels(const void* img, const void* depth, const void* tex) {
-  if (!img) { scsfm::g_ntexels = 0; return SCSFM_OK; }  // (nullptr: forget everything)
-  for (int i = 0; i < scsfm::g_ntexels; ++i)
-    if (scsfm::g_texels[i].img == img && scsfm::g_texels[i].depth == depth) { scsfm::g_texels[i].tex = tex; return SCSFM_OK; }
-  if (scsfm::g_ntexels >= 32) return SCSFM_ERR_ARG;
-  scsfm::g_texels[scsfm::g_ntexels++] = scsfm::TexelEntry{img, depth, tex};
-  return SCSFM_OK;
-}
-#endif
 #ifdef PROBE_TIMING
 int scsfm_probe_read(unsigned long long* host, size_t n) {
   (void)hipDeviceSynchronize();

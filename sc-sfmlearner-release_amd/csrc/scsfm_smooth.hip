@@ -13,9 +13,6 @@
 // the forward and once per direction in the backward (the left / upper edge of a pixel is the
 // previous lane's / row's right / lower edge).
 #include "scsfm_common.h"
-#ifndef SCSFM_RGBD
-#define SCSFM_RGBD 0
-#endif
 
 namespace scsfm {
 
@@ -54,13 +51,7 @@ struct SmoothFrame {
   const T* depth; const T* img; double* per_img; double* partials; T* out; T* g_depth;
   T* edge;  // optional plane [B,H,W]: sum over the pixel's four edges of +-sgn(dD) w / cnt, written by the
             // forward so that the backward is a pure stream (no image reads, no exp)
-#if SCSFM_RGBD
-  T* texels;  // optional [B,H,W,4]: the frame as (r, g, b, depth) texels, written by the forward
-#endif
 };
-#if SCSFM_RGBD
-const void* texels_of(const void* img, const void* depth);
-#endif
 template <typename T>
 struct SmoothBatch {
   SmoothFrame<T> f[kMaxFrames];
@@ -145,12 +136,6 @@ __global__ __launch_bounds__(kThreads) void smooth_fwd_kernel(SmoothBatch<T> sb,
     const T wx = ex ? edge_weight(cur, right) : T(0), wy = ey ? edge_weight(cur, down) : T(0);
     const T dx = cur.d - right.d, dy = cur.d - down.d;
     if (own_x && y < H) { sd += cur.d; sx += t_abs(dx) * wx; sy += t_abs(dy) * wy; }
-#if SCSFM_RGBD
-    if (fr.texels && own_x && y < H) {  // (workgroup-uniform pointer)
-      struct alignas(4 * sizeof(T)) Tx { T r, g, b, d; };
-      reinterpret_cast<Tx*>(fr.texels)[(size_t)b * plane + unsigned(y) * unsigned(W) + unsigned(x)] = Tx{cur.c0, cur.c1, cur.c2, cur.d};
-    }
-#endif
     if (edge) {  // workgroup-uniform
       const T tx = t_sgn(dx) * wx * icx, ty = t_sgn(dy) * wy * icy;
       const T tx_left = lane_left(tx);  // the pixel's left edge is its left neighbour's right edge
@@ -337,9 +322,6 @@ static SmoothFrame<T> make_frame(int B, int H, int W, const void* depth, const v
   f.per_img = reinterpret_cast<double*>((char*)ws + l.off_img);
   f.partials = reinterpret_cast<double*>((char*)ws + l.off_partials);
   f.out = out; f.g_depth = (T*)g_depth; f.edge = (T*)edge;
-#if SCSFM_RGBD
-  f.texels = (T*)texels_of(img, depth);
-#endif
   return f;
 }
 

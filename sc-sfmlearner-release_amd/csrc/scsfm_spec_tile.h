@@ -93,17 +93,6 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
   const DepthMap<T, kScaled> tgt_depth = depth_map<kScaled>(pa.tgt_depth, b, H, W, pa.ds);
   const DepthMap<T, kScaled> ref_depth = depth_map<kScaled>(pa.ref_depth, b, H, W, pa.ds);
   gbuf += (size_t)b * plane;
-#if SCSFM_RGBD
-  // kTex: every read of the reference frame -- un-warped colours, warp taps, ring taps, the tail's taps -- goes through
-  // its [H, W, 4] texel plane; nothing is staged for the tail
-  constexpr bool kTex = !kScaled && sizeof(T) == 4 && kSsim && TH == kTileH;
-  constexpr bool kTexTail = kTex && SCSFM_RGBD != 2;  // (SCSFM_RGBD=2: texels in the warp phase only, the tail as in the product)
-  constexpr bool kTexTgt = kTex && SCSFM_RGBD == 3;   // (SCSFM_RGBD=3: the target frame's streaming loads through its texel plane too)
-  const TexPlane<T> refT = tex_plane(pa.ref_tex + (size_t)b * plane * 4);
-  const TexPlane<T> tgtT = tex_plane((kTexTgt ? pa.tgt_tex : pa.ref_tex) + (size_t)b * plane * 4);
-#else
-  constexpr bool kTex = false, kTexTail = false, kTexTgt = false;
-#endif
 
   const int px = ox + col, py0 = oy + strip * STRIP;
   const bool in_x = col >= 1 && col <= kTileW - 2 && px < W;
@@ -138,30 +127,14 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     for (int k = 0; k < STRIP; ++k) {
       const int v = reflect_index(py0 + k, H);
       const unsigned off = (unsigned(v) * unsigned(W) + unsigned(u)) * unsigned(sizeof(T));
-#if SCSFM_RGBD
-      if constexpr (kTexTgt) {
-        const Texel<T> t = ld_texel(tgtT, unsigned(v) * unsigned(W) + unsigned(u));
-        in_d[k] = t.d; in_t[k][0] = t.r; in_t[k][1] = t.g; in_t[k][2] = t.b;
-      } else
-#endif
-      {
       in_d[k] = tgt_depth.at(u, v, off);
   #pragma unroll
       for (int c = 0; c < 3; ++c) in_t[k][c] = ld_plane(tgtP, c, off);
-      }
   #pragma unroll
       for (int c = 0; c < 3; ++c) in_r[k][c] = T(0);
       if (with_auto) {
-#if SCSFM_RGBD
-        if constexpr (kTex) {
-          const Texel<T> t = ld_texel(refT, unsigned(v) * unsigned(W) + unsigned(u));
-          in_r[k][0] = t.r; in_r[k][1] = t.g; in_r[k][2] = t.b;
-        } else
-#endif
-        {
   #pragma unroll
         for (int c = 0; c < 3; ++c) in_r[k][c] = ld_plane(refP, c, off);
-        }
       }
     }
     const bool has_ring = kSsim && threadIdx.x < 2 * kHaloW + 2 * TH;
@@ -170,17 +143,9 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
       ring_pos<TH>(threadIdx.x, rhy, rhx);
       ru = reflect_index(ox + rhx - 1, W); rv = reflect_index(oy + rhy - 1, H);
       const unsigned off = (unsigned(rv) * unsigned(W) + unsigned(ru)) * unsigned(sizeof(T));
-#if SCSFM_RGBD
-      if constexpr (kTexTgt) {
-        const Texel<T> t = ld_texel(tgtT, unsigned(rv) * unsigned(W) + unsigned(ru));
-        rin_d = t.d; rin_t[0] = t.r; rin_t[1] = t.g; rin_t[2] = t.b;
-      } else
-#endif
-      {
       rin_d = tgt_depth.at(ru, rv, off);
   #pragma unroll
       for (int c = 0; c < 3; ++c) rin_t[c] = ld_plane(tgtP, c, off);
-      }
     }
     // ---- phase 1a ------------------------------------------------------------------------------
     // SCSFM_W_GROUP pixels' gathers are in flight together (tools/march_timing.py: with one pixel after the other this
@@ -198,16 +163,9 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
       for (int j = 0; j < WG_; ++j) {
         const int k = k0 + j;
         sm[j] = project_pixel(bc, u, reflect_index(py0 + k, H), in_d[k], H, W, flags);
-#if SCSFM_RGBD
-        if constexpr (kTex) {
-          texel_rows(load_texel_block(refT, sm[j]), tc[j], td[j]);
-        } else
-#endif
-        {
   #pragma unroll
         for (int c = 0; c < 3; ++c) tc[j][c] = load_tap_rows(refP, c, sm[j]);
         td[j] = ref_depth.taps(sm[j]);
-        }
       }
       if (WG_ > 1) sched_fence();
   #pragma unroll
@@ -252,14 +210,6 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     if constexpr (kSsim) {
       if (has_ring) {
         const Sample<T> rs = project_pixel(bc, ru, rv, rin_d, H, W, flags);
-#if SCSFM_RGBD
-        if constexpr (kTex) {
-          TapRows<T> rc[3], rd_;
-          texel_rows(load_texel_block(refT, rs), rc, rd_);
-  #pragma unroll
-          for (int c = 0; c < 3; ++c) sXY[c][rhy][rhx] = make2(rin_t[c], bilerp_rows(rc[c], rs));
-        } else
-#endif
   #pragma unroll
         for (int c = 0; c < 3; ++c) sXY[c][rhy][rhx] = make2(rin_t[c], bilerp_rows(load_tap_rows(refP, c, rs), rs));
       }
@@ -443,7 +393,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     T* __restrict__ g_scatter = pa.gbuf + kPlaneScatter * gplane + (size_t)b * plane;
     if constexpr (!kSsim) scatter_box();  // (with SSIM: done after the warp phase's barrier)
     const bool wide = kWideOk && __builtin_amdgcn_readfirstlane(wrows) > WH;  // (uniform: every thread read the same boxes)
-    if constexpr (kStage && !SCSFM_STAGE_EARLY && !kTexTail) {
+    if constexpr (kStage && !SCSFM_STAGE_EARLY) {
       if (!wide) SCSFM_ISSUE_STAGE_LOADS();
     }
     T d_own[STRIP];  // depth of the owned pixels: kept since phase 0, or (kLean: 4 registers less across the SSIM phases) re-read
@@ -451,9 +401,6 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     for (int k = 0; k < STRIP; ++k) {
       if constexpr (kLean) {
         const int cy = py0 + k < H ? (py0 + k < 0 ? 0 : py0 + k) : H - 1, cx = px < W ? (px < 0 ? 0 : px) : W - 1;
-#if SCSFM_RGBD
-        if constexpr (kTexTgt) d_own[k] = ld_texel(tgtT, unsigned(cy) * unsigned(W) + unsigned(cx)).d; else
-#endif
         d_own[k] = tgt_depth.at(cx, cy, (unsigned(cy) * unsigned(W) + unsigned(cx)) * unsigned(sizeof(T)));
       } else {
         d_own[k] = in_d[k];
@@ -476,7 +423,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
         ww.rows = WH + 3 * kWideRows;
         ww.off = int(reinterpret_cast<Cell*>(sp_colour) - &win[0][0]) - WH * WW;
         ww.step = kTileFloats - kWideRows * WW;
-      } else if constexpr (!kTexTail) {
+      } else {
       // ... and go to LDS: the tiles and sG are dead by now
 #pragma unroll
       for (int i = 0; i <= NR; ++i) {
@@ -498,38 +445,6 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     // debugging launches count the wraps of the window's fixed-point cells (scsfm_geom.h: win_add); flags is a
     // compile-time constant without that bit in the product instantiation, so this is a constant nullptr there
     unsigned* const ovf = (flags & SCSFM_DEBUG_CHECK_WINDOW) ? window_overflow_counter(pa) : nullptr;
-#if SCSFM_RGBD
-#ifndef SCSFM_TAIL_GROUP  // pixels of the tail whose texel gathers are in flight together
-#define SCSFM_TAIL_GROUP 1
-#endif
-    if constexpr (kTexTail && SCSFM_TAIL_GROUP > 1) {
-      constexpr int TG = SCSFM_TAIL_GROUP;
-#pragma unroll
-      for (int k0 = 0; k0 < STRIP; k0 += TG) {
-        GeomTaps<T> f[TG];
-#pragma unroll
-        for (int j = 0; j < TG; ++j) {
-          const int py = py0 + k0 + j;
-          const int cy = py < H ? (py < 0 ? 0 : py) : H - 1, cx = px < W ? (px < 0 ? 0 : px) : W - 1;  // (an in-image address for rim pixels)
-          f[j].s = project_pixel(bc, cx, cy, d_own[k0 + j], H, W, flags);
-          texel_rows(load_texel_block(refT, f[j].s), f[j].tc, f[j].td);
-        }
-        sched_fence();
-#pragma unroll
-        for (int j = 0; j < TG; ++j) {
-          const int k = k0 + j, ly = strip * STRIP + k, py = py0 + k;
-          gd[k] = T(0);
-          if (!(in_x && ly >= 1 && ly <= TH - 2 && py < H) || (flags & SCSFM_DEBUG_X4)) continue;
-          T gI[3];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) gI[c] = reinterpret_cast<const T*>(&sXY[c][0][0])[(lrow + k) * kTileW + col];
-          gd[k] = geom_consume<T, Cell, WW, WH>(bc, f[j], px, py, d_own[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc, ww,
-                                                T(1), ovf);
-        }
-      }
-    } else
-#endif
-    {
 #pragma unroll
     for (int k = 0; k < STRIP; ++k) {
       const int ly = strip * STRIP + k, py = py0 + k;
@@ -540,15 +455,6 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
       for (int c = 0; c < 3; ++c) {
         if constexpr (kSsim) gI[c] = reinterpret_cast<const T*>(&sXY[c][0][0])[(lrow + k) * kTileW + col]; else gI[c] = gI_reg[k][c];
       }
-#if SCSFM_RGBD
-      if constexpr (kTexTail) {
-        GeomTaps<T> f;
-        f.s = project_pixel(bc, px, py, d_own[k], H, W, flags);
-        texel_rows(load_texel_block(refT, f.s), f.tc, f.td);
-        gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, d_own[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc, ww,
-                                              T(1), ovf);
-      } else
-#endif
       if constexpr (kStage) {
         const GeomTaps<T> f = geom_fetch<kStageRows, !kLean>(bc, px, py, d_own[k], refP, ref_depth, H, W, flags, staged);
         gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, d_own[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc, ww,
@@ -557,7 +463,6 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
         gd[k] = geom_pixel<T, Cell, WW, WH>(bc, px, py, d_own[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
                                       wy0, g_scatter, acc, T(1), ovf);
       }
-    }
     }
     // A barrier waits for every outstanding global store / atomic of the wave, so everything that writes to
     // global memory comes after the last barrier: the round trips of the dense stores and of the window's
