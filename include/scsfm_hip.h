@@ -179,6 +179,19 @@ typedef struct scsfm_pair_desc {
                       materialised up-sampled copy; g_tgt_depth / g_ref_depth receive the sum-pooled gradients */
   void* g_tgt_img; /* read by scsfm_pairs_bwd_inputs only; NULL or [B,3,H,W], ACCUMULATE (atomic adds): dL/d tgt_img of this */
   void* g_ref_img; /* pair-direction, dL/d ref_img likewise -- zero the buffers before the first call that names them */
+  /* ABI 9 -- get_smooth_loss (loss_functions.py:133-152) of this pair's TARGET frame evaluated by the speculative
+     forward, in the tile that holds the frame's depth and colours anyway (train.py:262-266 calls both losses on the same
+     frames; a separate pass over every frame costs 36 + 7 us per step at configs[1]).  Read by scsfm_pairs_fwd /
+     scsfm_pairs_fwd_step only, and only from descriptors with a gbuf and depth_shift 0 (anything else: argument error): */
+  void* smooth_ws;   /* NULL, or the frame's smooth workspace (scsfm_smooth_ws_bytes): receives {mean_HW(D) + 1e-7, L} per
+                        image exactly as scsfm_smooth_multi_fwd leaves them -- scsfm_smooth_multi_bwd and
+                        scsfm_pairs_bwd_smooth take it from there */
+  void* smooth_edge; /* with smooth_ws: NULL or [B,1,H,W] (store): every pixel's summed edge terms, bit for bit the plane
+                        scsfm_smooth_multi_fwd writes */
+  void* smooth_out;  /* with smooth_ws: 1 element (store) = this frame's loss */
+  void* smooth_total; /* read from d[0] only, may be NULL: 1 element (store) = the sum of smooth_out over the descriptors
+                         that carry a smooth_ws, in descriptor order = compute_smooth_loss (loss_functions.py:154-159)
+                         when each frame of the step is the target of exactly one of them */
 } scsfm_pair_desc;
 
 int scsfm_pairs_fwd_f32(int n, const scsfm_pair_desc* d, int B, int H, int W, const float* intrinsics,
@@ -188,6 +201,15 @@ int scsfm_pairs_bwd_f32(int n, const scsfm_pair_desc* d, int B, int H, int W, co
                         void* stream);
 int scsfm_pairs_fwd_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, const double* intrinsics,
                         unsigned flags, double w_photo, double w_geom, void* stream);
+/* ABI 9: scsfm_pairs_fwd that also forms the step's objective (train.py:268) in its finalize launch: step_out[4] (device,
+ * store) = { w_photo * photo + w_smooth * smooth + w_geom * geometry, photo, smooth, geometry } with photo / geometry the
+ * sums d[0].total receives and smooth the sum d[0].smooth_total receives (both must be non-NULL; n <= 8: one launch). */
+int scsfm_pairs_fwd_step_f32(int n, const scsfm_pair_desc* d, int B, int H, int W, const float* intrinsics,
+                             unsigned flags, double w_photo, double w_smooth, double w_geom, float* step_out,
+                             void* stream);
+int scsfm_pairs_fwd_step_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, const double* intrinsics,
+                             unsigned flags, double w_photo, double w_smooth, double w_geom, double* step_out,
+                             void* stream);
 int scsfm_pairs_bwd_f64(int n, const scsfm_pair_desc* d, int B, int H, int W, const double* intrinsics,
                         unsigned flags, void* scratch, const double* g_photo, const double* g_geom,
                         void* stream);

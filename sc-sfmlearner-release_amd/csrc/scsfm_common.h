@@ -51,8 +51,11 @@ struct BatchConsts {
 //                                 reduced by pose_reduce_bwd_kernel -- same-address atomics from ~200 blocks per
 //                                 image cost 60 us per launch, partials cost nothing)
 //   [off_partials]     partials : double[nblocks][3]
+//   [off_smooth]       smooth   : double[nblocks][waves per block][3] = {sum D, Sx, Sy} of the target frame's smooth loss, one
+//                                 record per wave of every tile (only written by a speculative forward whose descriptor
+//                                 names a smooth workspace)
 struct PairWs {
-  size_t off_sums, off_gP, off_partials, total;
+  size_t off_sums, off_gP, off_partials, off_smooth, total;
   int nbx, nby;
 };
 
@@ -83,6 +86,8 @@ inline PairWs pair_ws_layout(int B, int H, int W) {
   // partials: sized for the finest tiling that writes them (at most 62 x 6 outputs per block of the tiled kernels,
   // 60-column strips of the speculative forward)
   l.off_partials = off; off += (size_t)ceil_div(W, kTileW - 4) * ceil_div(H, 6) * B * 3 * sizeof(double);
+  // the target frame's smooth-loss partials of a pair that carries them (scsfm_pair_desc::smooth_ws): one record per tile
+  l.off_smooth = off; off += (size_t)ceil_div(W, kTileW - 4) * ceil_div(H, 6) * B * 3 * (kThreads / kWave) * sizeof(double);
   l.total = (off + 255) & ~(size_t)255;
   return l;
 }
@@ -234,6 +239,8 @@ __device__ __forceinline__ float t_min(float a, float b) { return __builtin_fmin
 __device__ __forceinline__ double t_min(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ float t_max(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ double t_max(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float t_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ double t_med3(double x, double lo, double hi) { return t_min(t_max(x, lo), hi); }
 template <typename T> __device__ __forceinline__ T t_sgn(T x) { return x > T(0) ? T(1) : (x < T(0) ? T(-1) : T(0)); }
 __device__ __forceinline__ float t_floor(float x) { return floorf(x); }
 __device__ __forceinline__ double t_floor(double x) { return floor(x); }
@@ -309,6 +316,29 @@ __device__ __forceinline__ double lane_right(double v) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 template <typename T> __device__ __forceinline__ T box3(T v) { return (v + lane_left(v)) + lane_right(v); }
+
+// Sum over the 64 lanes of a wave, valid in lane 63 ONLY: an inclusive scan by DPP (row shifts by 1, 2, 4, 8, then the
+// two row broadcasts -- the sequence of LLVM's atomic optimiser): six v_add_f32_dpp, no LDS traffic and no lane-index
+// arithmetic (a butterfly of ds_bpermute costs ~10 vector instructions per step in a block that has not formed the
+// lane's permute addresses yet).  The host simulation and fp64 take the butterfly (every lane then holds the sum).
+template <int kCtrl, int kRowMask, bool kBound>
+__device__ __forceinline__ float dpp_term(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, kRowMask, 0xf, kBound));
+}
+__device__ __forceinline__ float wave_sum_last(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v += dpp_term<0x111, 0xf, true>(v);  // row_shr:1
+  v += dpp_term<0x112, 0xf, true>(v);  // row_shr:2
+  v += dpp_term<0x114, 0xf, true>(v);  // row_shr:4
+  v += dpp_term<0x118, 0xf, true>(v);  // row_shr:8
+  v += dpp_term<0x142, 0xa, false>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_term<0x143, 0xc, false>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+#else
+  return wave_sum(v);
+#endif
+}
+__device__ __forceinline__ double wave_sum_last(double v) { return wave_sum(v); }
 
 
 }  // namespace scsfm

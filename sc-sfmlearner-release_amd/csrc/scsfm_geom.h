@@ -267,8 +267,6 @@ struct Sample {
   bool valid;       // max(|xn|, |yn|) <= 1   (inverse_warp.py:264)
 };
 
-__device__ __forceinline__ float t_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
-__device__ __forceinline__ double t_med3(double x, double lo, double hi) { return t_min(t_max(x, lo), hi); }
 
 template <typename T>
 __device__ __forceinline__ T clamp01_(T x) { return t_min(t_max(x, T(0)), T(1)); }
@@ -537,28 +535,44 @@ __device__ __forceinline__ void lds_add(T* p, T v) {
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Cells of the staging windows.  fp32 product path: 32-bit FIXED POINT (2^-20 per unit, range +-2048), because on
-// gfx950 the LDS float atomic is executed lane by lane (ds_add_f32: 1.25 ns per LANE per CU, measured with
-// tools/ubench/rates2.hip) while the integer one is a single pass (ds_add_u32: 2 ns per wave instruction);
-// contributions are rounded to nearest, so a cell's error is at most half a unit per contribution (4.8e-7) whatever
-// the order of the additions -- the window part of the scatter is bit-reproducible.  fp64 (gradient-check builds):
-// plain fp64 cells.
-// Range: a pixel whose (unscaled) gradient reaches kFixCap does not enter the window at all -- it takes the direct
-// fp32 atomics that taps outside the window take -- so a cell wraps only if more than 2048 / kFixCap = 32 pixels of
-// ONE tile (each just below the cap; typical magnitudes are below 10) pile their taps onto the same reference pixel:
-// an areal compression of the warp that no frame-to-frame motion produces -- but that the operator does not reject (a
-// scene scaled down a hundredfold with a forward motion of several depths and a photo-only upstream gradient wraps
-// cells: tests/test_hostsim_kernels.py).  Two guards: tiles whose whole footprint covers fewer than kCompressiveCells
-// cells bypass the window (uniform branch per tile), and launches with SCSFM_DEBUG_CHECK_WINDOW count every wrap
-// exactly (win_add) in a word of the pair's workspace; the Python wrapper raises on a non-zero count when
-// SCSFM_CHECK_WINDOW=1.
-#ifndef SCSFM_COMPRESSIVE_CELLS  // knob for the tests: 0 = no guard (the wrap detector of the debug launches then has something to find)
-#define SCSFM_COMPRESSIVE_CELLS 128
+// Cells of the staging windows.  fp32 speculative forward: 32-bit FIXED POINT, because on gfx950 the LDS float atomic is
+// executed lane by lane (ds_add_f32: 1.25 ns per LANE per CU, measured with tools/ubench/rates2.hip) while the integer one
+// is a single pass (ds_add_u32: 2 ns per wave instruction); contributions are rounded to nearest, so a cell's error is at
+// most half a unit per contribution whatever the order of the additions -- the window part of the scatter is
+// bit-reproducible.  fp64 (gradient-check builds) and the fallback geometry pass: floating cells.
+//
+// Range (round 6: an exact, always-on guarantee instead of round 5's bounding-box heuristic).  A cell counts in units of
+// 2^-e, and e is chosen PER TILE from an upper bound of everything the tile can add to ONE cell: every pixel that enters
+// the window adds at most |g| (its four weights are <= 1) with |g| < kFixCap (larger terms take the direct fp32 atomics),
+// and |g| = |dL/d diff_depth| 2 Z / (Z + D_p)^2 <= (|r| + 3 [weight mask]) 2 Z / (Z + D_p)^2 =: u -- known in the warp
+// phase, when Z and D_p are in registers (|dL/d diff_depth| <= |r| m + m sum_c blend_c and every blend_c <= 1).  With
+// U = sum over the tile's owned, unmasked pixels of min(u, kFixCap), no cell can exceed U 2^e + 4 * 868 / 2 (rounding) in
+// magnitude, so e = min(20, floor(log2(kFixLimit / U))) cannot wrap -- whatever the warp does to the tile (round 5 found
+// a reachable wrap: a scene scaled down a hundredfold after a forward motion of several depths; a NON-uniform compression
+// inside a large footprint escaped its heuristic).  U <= 2002 -- every tile of an ordinary warp -- keeps e = 20: the same
+// cells, bit for bit, as before.  Cost: 7 vector instructions per pixel and one more value in the bounding box's wave
+// reduction.  Launches with SCSFM_DEBUG_CHECK_WINDOW still count every wrap exactly (win_add): the count is now 0 by
+// construction, and -DSCSFM_WINDOW_BOUND=0 (tests) switches the bound off to show that the detector works.
+#ifndef SCSFM_WINDOW_BOUND
+#define SCSFM_WINDOW_BOUND 1
 #endif
-constexpr int kCompressiveCells = SCSFM_COMPRESSIVE_CELLS;  // tiles whose scatter footprint is smaller than this bypass the window (spec_tile, geom_tile)
-constexpr float kFixScale = 1048576.0f;
+constexpr float kFixScale = 1048576.0f;  // 2^20: the unit of a tile whose bound allows it (all but pathological warps)
 constexpr float kFixInv = 1.0f / 1048576.0f;
 constexpr float kFixCap = 64.0f;
+constexpr float kFixLimit = 2.1e9f;  // < 2^31 - 4 * 1024 * 0.5 (rounding of every contribution) with room for the bound's own rounding
+// (scale, 1 / scale) of a tile from its bound U (uniform over the workgroup)
+__device__ __forceinline__ void win_units_of(float U, float& scale, float& inv) {
+  scale = kFixScale; inv = kFixInv;
+#if SCSFM_WINDOW_BOUND
+  const float room = kFixLimit / (U * 1.001f);  // (1.001: the bound is evaluated in fp32, a few ulp either way)
+  if (!(room >= kFixScale)) {  // (also taken by a NaN bound: the coarsest unit)
+    // 2^floor(log2(room)): the exponent field of room, mantissa cleared; never below 2^-20 (U <= 1024 * kFixCap)
+    const unsigned bits = __builtin_bit_cast(unsigned, room > 9.5367431640625e-7f ? room : 9.5367431640625e-7f) & 0x7f800000u;
+    scale = __builtin_bit_cast(float, bits);
+    inv = __builtin_bit_cast(float, (254u << 23) - bits);  // 2^-k for scale = 2^k
+  }
+#endif
+}
 __device__ __forceinline__ bool win_fits(const int*, float g) { return t_abs(g) < kFixCap; }
 __device__ __forceinline__ bool win_fits(const double*, double) { return true; }
 __device__ __forceinline__ bool win_fits(const float*, float) { return true; }
@@ -575,11 +589,10 @@ __device__ __forceinline__ int cvt_round_half_up(float x) {
   return (int)floorf(x + 0.5f);
 #endif
 }
-// A value in the unit a cell counts in (the power-of-two scale is exact, so it is applied to the pixel's gradient once
-// instead of to each of its four weighted taps) ...
-__device__ __forceinline__ float win_unit(const int*, float g) { return g * kFixScale; }
-__device__ __forceinline__ double win_unit(const double*, double g) { return g; }
-__device__ __forceinline__ float win_unit(const float*, float g) { return g; }
+// The scale a window of these cells counts in when the caller names none: 2^20 for fixed point, 1 for floating cells.
+template <typename Cell> struct WinScale0 { static constexpr double value = 1.0; };
+template <> struct WinScale0<int> { static constexpr double value = 1048576.0; };
+template <typename Cell, typename T> __device__ __forceinline__ T win_scale0() { return T(WinScale0<Cell>::value); }
 // ... added to a cell
 // `ovf` (SCSFM_DEBUG_CHECK_WINDOW launches only; nullptr -- a compile-time constant in the product instantiation --
 // otherwise): the add returns the cell's previous value and a signed 32-bit wrap is counted in *ovf (a global word of
@@ -596,7 +609,7 @@ __device__ __forceinline__ void win_add(int* p, float units, unsigned* ovf = nul
 }
 __device__ __forceinline__ void win_add(double* p, double v, unsigned* = nullptr) { lds_add(p, v); }
 __device__ __forceinline__ void win_add(float* p, float v, unsigned* = nullptr) { lds_add(p, v); }  // (float cells: see geom_tile)
-__device__ __forceinline__ float win_value(int c) { return float(c) * kFixInv; }
+__device__ __forceinline__ float win_value(int c) { return float(c); }  // (in the cell's unit: the flush multiplies by 1 / scale)
 __device__ __forceinline__ double win_value(double c) { return c; }
 __device__ __forceinline__ float win_value(float c) { return c; }
 
@@ -618,20 +631,18 @@ __device__ __forceinline__ int wide_adjust(const WideWin& ww, int ly) {  // only
   return e >= 0 ? ww.off + r * ww.step : 0;
 }
 
-// inv_unit (the fallback geometry pass): the window counts in units of 1 / inv_unit -- that pass scatters values that
-// already carry the 1e-7-sized factor of the masked mean, far below the fixed-point cells' resolution, so it stages
-// g * inv_unit (inv_unit = 1 / max(|a|, |b|) of its pair: magnitudes as in the speculative forward) and its flush
-// multiplies the cells by the unit again; taps that bypass the window add the unscaled g.
+// `scale`: what a value is multiplied with on its way into a cell -- the tile's 2^e for fixed-point cells (win_units_of),
+// 1 for floating cells; the flush multiplies the cells by its reciprocal.  Taps that bypass the window add g itself.
 template <typename T, typename Cell, int WW, int WH>
 __device__ __forceinline__ void scatter_taps_window(Cell (*win)[WW], int wx0, int wy0,
                                                     T* __restrict__ gplane, const Sample<T>& s, T g,
-                                                    const WideWin& ww = WideWin{WH, 0, 0}, T inv_unit = T(1),
+                                                    const WideWin& ww = WideWin{WH, 0, 0}, T scale = win_scale0<Cell, T>(),
                                                     unsigned* ovf = nullptr) {
   if (g == T(0)) return;
   const int lx = s.xa - wx0, ly = s.ya - wy0;
-  if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < ww.rows - 1 && win_fits(&win[0][0], g * inv_unit)) {
+  if (lx >= 0 && lx < WW - 1 && ly >= 0 && ly < ww.rows - 1 && win_fits(&win[0][0], g)) {
     // unpredicated: a cell of the block that is not a tap has weight 0, and adding 0 leaves it at the 0 the flush skips
-    const T gu = win_unit(&win[0][0], g * inv_unit);
+    const T gu = g * scale;  // (a power of two for fixed-point cells: exact, applied once instead of per tap)
     Cell* rn = &win[0][0] + ly * WW + lx;
     Cell* rs = rn + WW;
     if (ww.rows > WH) { rn += wide_adjust<WH>(ww, ly); rs += wide_adjust<WH>(ww, ly + 1); }  // (uniform branch)
@@ -647,7 +658,7 @@ __device__ __forceinline__ void scatter_taps_window(Cell (*win)[WW], int wx0, in
 // Only cells that received an in-image tap are non-zero, so every flushed cell is a valid pixel.
 template <typename T, typename Cell, int WW, int WH>
 __device__ __forceinline__ void flush_scatter_window(const Cell (*win)[WW], int wx0, int wy0,
-                                                     T* __restrict__ gplane, int W, T unit = T(1)) {
+                                                     T* __restrict__ gplane, int W, T unit = T(1) / win_scale0<Cell, T>()) {
   for (int i = threadIdx.x; i < WW * WH; i += kThreads) {
     const int ly = i / WW, lx = i - ly * WW;
     const Cell v = win[ly][lx];
@@ -668,7 +679,7 @@ __device__ __forceinline__ void atomic_add_at(T* __restrict__ base, unsigned byt
 template <typename T, typename Cell, int WW, int WH, int NT = kThreads>
 __device__ __forceinline__ void flush_scatter_region(const Cell (*win)[WW], int wx0, int wy0, int cx0,
                                                      int cy0, int cx1, int cy1, T* __restrict__ gplane, int W,
-                                                     const WideWin& ww = WideWin{WH, 0, 0}) {
+                                                     const WideWin& ww = WideWin{WH, 0, 0}, T inv = T(1) / win_scale0<Cell, T>()) {
   cx0 = cx0 < 0 ? 0 : cx0; cy0 = cy0 < 0 ? 0 : cy0;
   cx1 = cx1 > WW - 1 ? WW - 1 : cx1; cy1 = cy1 > ww.rows - 1 ? ww.rows - 1 : cy1;
   const int w = cx1 - cx0 + 1, h = cy1 - cy0 + 1;
@@ -692,8 +703,8 @@ __device__ __forceinline__ void flush_scatter_region(const Cell (*win)[WW], int 
     const bool second = i + NT < n;
     const Cell v0 = (&win[0][0])[cell_of(ry, rx)];
     const Cell v1 = second ? (&win[0][0])[cell_of(ry2, rx2)] : Cell(0);
-    if (v0 != Cell(0)) atomic_add_at(gplane, dest_of(ry, rx), T(win_value(v0)));
-    if (v1 != Cell(0)) atomic_add_at(gplane, dest_of(ry2, rx2), T(win_value(v1)));
+    if (v0 != Cell(0)) atomic_add_at(gplane, dest_of(ry, rx), T(win_value(v0)) * inv);
+    if (v1 != Cell(0)) atomic_add_at(gplane, dest_of(ry2, rx2), T(win_value(v1)) * inv);
     ry = ry2 + dq; rx = rx2 + dr;
     if (rx >= w) { rx -= w; ++ry; }
   }
@@ -702,7 +713,7 @@ __device__ __forceinline__ void flush_scatter_region(const Cell (*win)[WW], int 
     const int ry = int((float(i) + 0.5f) * iw);  // i / w, exact for the few thousand cells of a window
     const int ly = cy0 + ry, lx = cx0 + (i - ry * w);
     const Cell v = (&win[0][0])[ly * WW + lx + (ww.rows > WH ? wide_adjust<WH>(ww, ly) : 0)];
-    if (v != Cell(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), T(win_value(v)));
+    if (v != Cell(0)) atomicAdd(gplane + unsigned(wy0 + ly) * unsigned(W) + unsigned(wx0 + lx), T(win_value(v)) * inv);
   }
 #endif
 }
@@ -792,7 +803,7 @@ template <typename T, typename Cell, int WW, int WH>
 __device__ __forceinline__ T geom_consume(const BatchConsts<T>& bc, const GeomTaps<T>& f, int px, int py, T d, const T (&gI)[3], T g_dd,
                                           int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
                                           T* __restrict__ scatter_plane, T* acc, const WideWin& ww = WideWin{WH, 0, 0},
-                                          T inv_unit = T(1), unsigned* ovf = nullptr) {
+                                          T scale = win_scale0<Cell, T>(), unsigned* ovf = nullptr) {
   const Sample<T>& s = f.s;
   const TapRows<T>(&tc)[3] = f.tc;
   const TapRows<T>& td = f.td;
@@ -815,17 +826,18 @@ __device__ __forceinline__ T geom_consume(const BatchConsts<T>& bc, const GeomTa
   t.s.b = gI[0] * tc[0].s.b + gI[1] * tc[1].s.b + gI[2] * tc[2].s.b + gDp * td.s.b;
   T gix, giy;
   tap_rows_grad(t, s, gix, giy);
-  if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, Cell, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp, ww, inv_unit, ovf);
+  if (!(flags & SCSFM_DEBUG_X1)) scatter_taps_window<T, Cell, WW, WH>(win, wx0, wy0, scatter_plane, s, gDp, ww, scale, ovf);
   return pixel_geometry_bwd(bc, s, px, py, d, gix, giy, gZ, H, W, acc);
 }
 template <typename T, typename Cell, int WW, int WH, typename Map>
 __device__ __forceinline__ T geom_pixel(const BatchConsts<T>& bc, int px, int py, T d, const T (&gI)[3], T g_dd,
                                         const T* __restrict__ ref_img, const Map& ref_depth,
                                         unsigned plane, int H, int W, unsigned flags, Cell (*win)[WW], int wx0, int wy0,
-                                        T* __restrict__ scatter_plane, T* acc, T inv_unit = T(1), unsigned* ovf = nullptr) {
+                                        T* __restrict__ scatter_plane, T* acc, T scale = win_scale0<Cell, T>(),
+                                        unsigned* ovf = nullptr) {
   const GeomTaps<T> f = geom_fetch(bc, px, py, d, ref_img, ref_depth, plane, H, W, flags);
   return geom_consume<T, Cell, WW, WH>(bc, f, px, py, d, gI, g_dd, H, W, flags, win, wx0, wy0, scatter_plane, acc,
-                                       WideWin{WH, 0, 0}, inv_unit, ovf);
+                                       WideWin{WH, 0, 0}, scale, ovf);
 }
 
 }  // namespace scsfm

@@ -40,6 +40,11 @@ struct PairArgs {
   BatchConsts<T>* consts; double* sums; double* partials; double* gPp;
   T* out; T* gbuf; T* g_ref_depth; T* g_pose;
   int ds;  // log2 of the down-scale of BOTH depth maps of this pair (scsfm_pair_desc::depth_shift)
+  // scsfm_pair_desc::smooth_ws (speculative forward only): this pair also evaluates get_smooth_loss of its TARGET frame
+  double* sm_partials;  // nullptr = no; else double[B][tiles per image][3] in the pair's workspace: {sum D, Sx, Sy} per tile
+  T* sm_edge;           // nullptr or the frame's edge plane [B,H,W]
+  double* sm_img;       // the frame's {mean + 1e-7, L} per image (the start of its smooth workspace)
+  T* sm_out;            // nullptr or 1 element: the frame's loss
 };
 constexpr int kMaxPairs = 8;
 // Planes of a pair's gbuf (each B x H x W): what the tiled pass hands to the geometry pass, and the geometry
@@ -286,10 +291,18 @@ __device__ __forceinline__ void publish_losses(double Sp, double Sg, double Sm, 
 // the coefficients the backward multiplies the upstream gradients with.
 // `total` (optional): the sums over all pair-directions of a call of the two losses -- what
 // compute_photo_and_geometry_loss returns -- finished by whichever block comes last, in pair order.
+// The step's objective formed by the finalize launch (scsfm_pairs_fwd_step): out[4] = {w1 photo + w2 smooth + w3 geometry,
+// photo, smooth, geometry}; out == nullptr: not wanted.
+template <typename T>
+struct StepTotal {
+  T* smooth_total;  // nullptr or 1 element: the sum of the frames' smooth losses (scsfm_pair_desc::smooth_total)
+  T* out;
+  T w1, w2, w3;
+};
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb, int nblocks, int nblk_img, double spec,
                                                                  double w_photo, double w_geom, T* total, int first,
-                                                                 const double* __restrict__ hint) {
+                                                                 const double* __restrict__ hint, StepTotal<T> st, int H, int W) {
   __shared__ double red[3 * (kThreads / kWave)];
   const PairArgs<T>& pa = pb.p[blockIdx.x];
   const double* __restrict__ partials = pa.partials;
@@ -313,6 +326,38 @@ __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb
     for (int j = 0; j < U; ++j) { v[0] += q[j][0]; v[1] += q[j][1]; v[2] += q[j][2]; }
   }
   block_sum<3>(v, red);
+  if (pa.sm_partials != nullptr) {
+    // the target frame's smooth loss from the tiles' {sum D, Sx, Sy} records (smooth_finalize_kernel's arithmetic: each
+    // wave reduces whole images with shuffles, in a fixed order, then the waves' contributions meet in LDS)
+    __shared__ double sm_red[kThreads / kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, B = nblocks / nblk_img;
+    const int nrec = nblk_img * (kThreads / kWave);  // one record per wave of every tile of an image
+    const double cnt_x = (double)B * H * (W - 1), cnt_y = (double)B * (H - 1) * W;
+    double loss = 0.0;
+    for (int b = wave; b < B; b += kThreads / kWave) {
+      double v0 = 0, v1 = 0, v2 = 0;
+      for (int i = lane; i < nrec; i += 2 * kWave) {  // (two records per lane in flight)
+        const bool two = i + kWave < nrec;
+        const double* q = pa.sm_partials + 3 * ((size_t)b * nrec + i);
+        const double* r = pa.sm_partials + 3 * ((size_t)b * nrec + (two ? i + kWave : i));
+        const double a0 = q[0], a1 = q[1], a2 = q[2], b0 = r[0], b1 = r[1], b2 = r[2];
+        v0 += a0; v1 += a1; v2 += a2;
+        if (two) { v0 += b0; v1 += b1; v2 += b2; }
+      }
+      v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
+      const double den = v0 / ((double)H * W) + 1e-7;  // mean_HW(D) + 1e-7, loss_functions.py:139-140
+      const double L = v1 / cnt_x + v2 / cnt_y;
+      if (lane == 0) { pa.sm_img[2 * b] = den; pa.sm_img[2 * b + 1] = L; }
+      loss += L / den;
+    }
+    if (lane == 0) sm_red[wave] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0 && pa.sm_out) {
+      double t = 0;
+      for (int w = 0; w < kThreads / kWave; ++w) t += sm_red[w];
+      pa.sm_out[0] = T(t);
+    }
+  }
   if (threadIdx.x == 0) {
     publish_losses(v[0], v[1], v[2], sums, out);
     out[7] = T(*window_overflow_counter(pa));  // (0 unless the forward was launched with SCSFM_DEBUG_CHECK_WINDOW and a cell wrapped)
@@ -333,6 +378,16 @@ __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb
         }
         total[0] = first ? photo : total[0] + photo;
         total[1] = first ? geom : total[1] + geom;
+        if (st.smooth_total) {  // the frames' smooth losses, in descriptor order
+          T smooth = T(0);
+          for (unsigned i = 0; i < gridDim.x; ++i)
+            if (pb.p[i].sm_partials && pb.p[i].sm_out) smooth += *const_cast<const volatile T*>(pb.p[i].sm_out);
+          st.smooth_total[0] = first ? smooth : st.smooth_total[0] + smooth;
+          if (st.out) {
+            st.out[0] = st.w1 * total[0] + st.w2 * st.smooth_total[0] + st.w3 * total[1];
+            st.out[1] = total[0]; st.out[2] = st.smooth_total[0]; st.out[3] = total[1];
+          }
+        }
       }
     }
   }
@@ -420,9 +475,10 @@ namespace scsfm {
 template <typename T, bool kSsim, unsigned kFlags = kRuntimeFlags, bool kScaled = false, bool kStageFwd = false>
 __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? SCSFM_PHOTO_BLOCKS : 1) void pair_fwd_spec_kernel(PairBatch<T> pb, int B, int H, int W,
                                                                                   unsigned flags, T r_hint,
-                                                                                  const double* __restrict__ hint) {
+                                                                                  const double* __restrict__ hint, T sm_icx, T sm_icy) {
   if (hint) r_hint = hint[0] != 0.0 ? T(3.0 * hint[1] / hint[0]) : T(0);  // (scsfm_pair_desc::hint: the device's pair wins)
-  spec_tile<T, kSsim, kScaled, kFlags, kStageFwd>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, pb, B, H, W, flags, nullptr, nullptr, r_hint);
+  spec_tile<T, kSsim, kScaled, kFlags, kStageFwd>(xcd_block_id(), (int)gridDim.x, (int)gridDim.y, pb, B, H, W, flags, nullptr, nullptr, r_hint,
+                                                  sm_icx, sm_icy);
 }
 #ifdef SCSFM_WITH_MARCH
 #ifndef SCSFM_MARCH_WAVES_PER_SIMD  // waves per SIMD the march is compiled for (168 VGPRs at 3: no spills; 128 at 4: spills)
@@ -660,21 +716,15 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
   double* __restrict__ gP = pa.gPp;
   constexpr int ROWS = kGeomRows;  // pixels per thread: a block covers a 64 x (4 ROWS) tile
   __shared__ double red[12 * (kThreads / kWave)];
-  // Fixed-point cells, as in the speculative forward (an LDS float atomic serialises per lane on gfx950: the float
-  // window of rounds 1-3 cost this pass 5 us per tile), counted in units of the pair's own coefficient: this pass runs
-  // with the FINAL coefficients a = g_photo / (3 S_m), b = g_geom / S_m (~1e-7), so the values it stages are divided by
-  // max(|a|, |b|) -- magnitudes of a few units, like the speculative forward's unscaled terms -- and the flush
-  // multiplies the cells by it again.  fp64 (gradient checks): floating cells, unit 1.
-  typedef typename WinCell<T>::type Cell;
+  // FLOATING cells (round 6).  Rounds 4-5 staged this pass's scatter in the fixed-point cells of the speculative forward
+  // (-10 us on a pass that runs once per change of the loss weights) behind a two-corner compression heuristic; unlike
+  // the speculative tile this pass has no cheap bound of what a tile adds to one cell before it scatters (its terms carry
+  // the final coefficients and Z, D_p only exist per pixel), so the exact guarantee here is a cell that cannot wrap: the
+  // LDS float atomic, lane by lane.  Order-dependent in the last ulp, like the direct atomics of the taps that miss the
+  // window (and like grid_sampler_2d_backward itself, inverse_warp.py:267).
+  typedef T Cell;
   __shared__ Cell win[kWinH][kWinW];  // staging window of the scatter into dL/d ref_depth
   if (T(sums[5]) * g_photo[0] == T(0) && T(sums[6]) * g_geom[0] == T(0)) return;  // as in pass A
-  const T ca = t_abs(T(sums[5]) * g_photo[0]), cb_ = t_abs(T(sums[6]) * g_geom[0]);
-  // What this pass scatters is dL/d diff_depth = b m - [mask] a m blend: without the weight mask only the geometry
-  // coefficient is in it, so the unit is |b| alone (with |a| >> |b| the cells would otherwise resolve |b|-sized values
-  // with 2^-20 |a|: per cents).  A unit of 0 (nothing to scatter) or in the subnormal range (1 / unit overflows) is
-  // raised to FLT_MIN: the staged values then stay finite and at most as large as with the true unit.
-  const T want = (flags & SCSFM_WITH_MASK) ? (ca > cb_ ? ca : cb_) : cb_;
-  const T unit = sizeof(T) == 4 ? (want > T(1.17549435e-38f) ? want : T(1.17549435e-38f)) : T(1), inv_unit = T(1) / unit;
   if (spec_valid(sums, g_photo, g_geom)) return;  // the speculative forward already ran this pass in its tail
   const int px = blk.x * kWave + (threadIdx.x & (kWave - 1));
   const int py0 = (blk.y * (kThreads / kWave) + threadIdx.x / kWave) * ROWS;
@@ -695,18 +745,6 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
   int wx0, wy0;
   window_origin<T, kWinW, kWinH>(bc, blk.x * kWave + kWave / 2, blk.y * (kThreads / kWave) * ROWS + 2 * ROWS, tgt_depth,
                                  H, W, flags, wx0, wy0);
-  if (sizeof(Cell) == 4) {
-    // The guard of the speculative forward's window (scsfm_spec_tile.h: scatter_box) for this pass, which has no
-    // bounding box of its taps: two opposite corners of the tile are projected; if both land inside the reference view
-    // within a footprint of fewer than kCompressiveCells cells, the warp compresses the tile's 1024 pixels so much that
-    // a fixed-point cell could wrap -- the tile then scatters with direct fp32 atomics (window out of every tap's reach).
-    const int x0 = blk.x * kWave, y0 = blk.y * (kThreads / kWave) * ROWS;
-    const int x1 = t_clampi(x0 + kWave - 1, 0, W - 1), y1 = t_clampi(y0 + (kThreads / kWave) * ROWS - 1, 0, H - 1);
-    const Sample<T> c0 = project_pixel(bc, x0, y0, tgt_depth.at(x0, y0, (unsigned(y0) * unsigned(W) + unsigned(x0)) * unsigned(sizeof(T))), H, W, flags);
-    const Sample<T> c1 = project_pixel(bc, x1, y1, tgt_depth.at(x1, y1, (unsigned(y1) * unsigned(W) + unsigned(x1)) * unsigned(sizeof(T))), H, W, flags);
-    const int ex = (c1.xa > c0.xa ? c1.xa - c0.xa : c0.xa - c1.xa) + 2, ey = (c1.ya > c0.ya ? c1.ya - c0.ya : c0.ya - c1.ya) + 2;
-    if (c0.valid && c1.valid && ex * ey < kCompressiveCells) wx0 = 1 << 28;
-  }
   T acc[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) acc[i] = T(0);
@@ -729,12 +767,11 @@ __device__ __forceinline__ void geom_tile(const BlockId blk, int nbx, int nby, c
     if (px >= W || py >= H) continue;
     const T gI[3] = {in_g[r][0], in_g[r][1], in_g[r][2]};
     const T gd = geom_pixel<T, Cell, kWinW, kWinH>(bc, px, py, in_d[r], gI, in_g[r][3], ref_img, ref_depth, plane, H, W, flags,
-                                             win, wx0, wy0, g_scatter, acc, inv_unit,
-                                             (flags & SCSFM_DEBUG_CHECK_WINDOW) ? window_overflow_counter(pa) : nullptr);
+                                             win, wx0, wy0, g_scatter, acc, T(1), nullptr);
     st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), (flags & SCSFM_DEBUG_X2) ? T(0) : gd);
   }
   __syncthreads();
-  if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5))) flush_scatter_window<T, Cell, kWinW, kWinH>(win, wx0, wy0, g_scatter, W, unit);
+  if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5))) flush_scatter_window<T, Cell, kWinW, kWinH>(win, wx0, wy0, g_scatter, W, T(1));
   if (flags & SCSFM_DEBUG_X3) {  // profiling: keep the partials defined
     if (threadIdx.x == 0)
       for (int i = 0; i < 12; ++i) gP[12 * ((size_t)(b * nby + blk.y) * nbx + blk.x) + i] = 0.0;
@@ -1150,6 +1187,13 @@ static PairArgs<T> make_pair_args(const scsfm_pair_desc& d, int B, int H, int W,
   a.g_ref_depth = (T*)d.g_ref_depth;
   a.g_pose = (T*)d.g_pose;
   a.ds = d.depth_shift;
+  a.sm_partials = nullptr; a.sm_edge = nullptr; a.sm_img = nullptr; a.sm_out = nullptr;
+  if (d.smooth_ws) {  // (only the speculative forward acts on it: pairs_fwd checks the descriptor)
+    a.sm_partials = reinterpret_cast<double*>(base + l.off_smooth);
+    a.sm_edge = (T*)d.smooth_edge;
+    a.sm_img = reinterpret_cast<double*>(d.smooth_ws);
+    a.sm_out = (T*)d.smooth_out;
+  }
   return a;
 }
 
@@ -1208,9 +1252,13 @@ static int march_seg_rows(int H, int chunk, int units) {
 // Forward of up to kMaxPairs pair-directions per launch.  `spec`: every pair has a gbuf and w_photo != 0.
 template <typename T>
 static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags, bool spec,
-                           double w_photo, double w_geom, T* total, bool first, const double* hint, hipStream_t stream) {
+                           double w_photo, double w_geom, T* total, bool first, const double* hint, hipStream_t stream,
+                           const StepTotal<T>& st) {
   PairBatch<T> pb;
-  for (int i = 0; i < n; ++i) pb.p[i] = make_pair_args<T>(d[i], B, H, W, nullptr, i);
+  for (int i = 0; i < n; ++i) {
+    pb.p[i] = make_pair_args<T>(d[i], B, H, W, nullptr, i);
+    if (!spec) pb.p[i].sm_partials = nullptr;  // (pairs_fwd rejected such descriptors already)
+  }
   const bool kernel_only = (flags & SCSFM_DEBUG_KERNEL_ONLY) != 0;  // profiling: consts are in place already
   // a launch with a coarser scale's maps in it runs the kernels instantiated for the index map (DepthMap)
   bool full_res = true;
@@ -1221,13 +1269,15 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
     if (!kernel_only)
       hipLaunchKernelGGL((pairs_zero_prep_kernel<T>), dim3(1024 + 1, n), dim3(kThreads), 0, stream, pb, npx, n, B, K);
     const T r_hint = w_photo != 0.0 ? T(3.0 * w_geom / w_photo) : T(0);
+    // reciprocal edge counts of get_smooth_loss's two means (loss_functions.py:150-152), as smooth_fwd_kernel rounds them
+    const T sm_icx = T(1.0 / ((double)B * H * (W - 1))), sm_icy = T(1.0 / ((double)B * (H - 1) * W));
     const bool timed = g_profile.used < g_profile.n;
     if (timed) (void)hipEventRecord(g_profile.start[g_profile.used], stream);
     if (!spec_uses_march()) {
       grid = dim3(ceil_div(W, kTileW - 2), ceil_div(H, Tile<T>::kH - 2), n * B);
 #define SCSFM_LAUNCH_SPEC(...)                                                                                          \
   hipLaunchKernelGGL((pair_fwd_spec_kernel<T, __VA_ARGS__>), grid, dim3(kThreads), debug_extra_lds(), stream, pb, B, H, W, \
-                     flags & ~SCSFM_DEBUG_KERNEL_ONLY, r_hint, hint)
+                     flags & ~SCSFM_DEBUG_KERNEL_ONLY, r_hint, hint, sm_icx, sm_icy)
       if (!full_res && (flags & SCSFM_WITH_SSIM)) SCSFM_LAUNCH_SPEC(true, kRuntimeFlags, true);
       else if (!full_res) SCSFM_LAUNCH_SPEC(false, kRuntimeFlags, true);
 #ifdef SCSFM_WITH_MARCH
@@ -1269,13 +1319,13 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
   if (!kernel_only)
     hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(n), dim3(kThreads), 0, stream, pb, (int)(grid.x * grid.y * B),
                        (int)(grid.x * grid.y), spec ? 1.0 : 0.0, spec ? w_photo : 0.0, spec ? w_geom : 0.0, total, first ? 1 : 0,
-                       spec ? hint : nullptr);
+                       spec ? hint : nullptr, st, H, W);
   return launch_status();
 }
 
 template <typename T>
 static int pairs_fwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags, double w_photo,
-                     double w_geom, void* stream_) {
+                     double w_geom, void* stream_, T* step_out = nullptr, double w_smooth = 0.0) {
   clear_status();
   if (n < 0 || (n > 0 && !d) || B <= 0 || H < 2 || W < 2 || !dims_ok<T>(B, H, W) || !K) return SCSFM_ERR_ARG;
   for (int i = 0; i < n; ++i)
@@ -1284,12 +1334,24 @@ static int pairs_fwd(int n, const scsfm_pair_desc* d, int B, int H, int W, const
   // maximal runs of descriptors with the same mode (speculative or plain), at most kMaxPairs each
   const double* hint = n > 0 ? (const double*)d[0].hint : nullptr;
   const bool may_spec = w_photo != 0.0 || hint != nullptr;
+  // the smooth loss rides in the speculative tile only, on full-resolution maps (scsfm_pair_desc::smooth_ws); the
+  // experimental forwards of tuning builds do not carry it
+  for (int i = 0; i < n; ++i)
+    if (d[i].smooth_ws && (!(d[i].gbuf && may_spec) || d[i].depth_shift != 0 || spec_uses_march() || spec_stages_fwd()))
+      return SCSFM_ERR_ARG;
+  StepTotal<T> st;
+  st.smooth_total = n > 0 ? (T*)d[0].smooth_total : nullptr;
+  st.out = step_out; st.w1 = T(w_photo); st.w2 = T(w_smooth); st.w3 = T(w_geom);
+  if (step_out && (n <= 0 || n > kMaxPairs || !d[0].total || !d[0].smooth_total)) return SCSFM_ERR_ARG;
+  if (step_out)  // (one finalize launch must see every pair: a single run of one mode)
+    for (int i = 1; i < n; ++i)
+      if ((d[i].gbuf != nullptr && may_spec) != (d[0].gbuf != nullptr && may_spec)) return SCSFM_ERR_ARG;
   int i = 0;
   while (i < n) {
     const bool spec = d[i].gbuf != nullptr && may_spec;
     int j = i + 1;
     while (j < n && j - i < kMaxPairs && ((d[j].gbuf != nullptr && may_spec) == spec)) ++j;
-    int rc = pairs_fwd_chunk<T>(j - i, d + i, B, H, W, K, flags, spec, w_photo, w_geom, (T*)d[0].total, i == 0, hint, stream);
+    int rc = pairs_fwd_chunk<T>(j - i, d + i, B, H, W, K, flags, spec, w_photo, w_geom, (T*)d[0].total, i == 0, hint, stream, st);
     if (rc) return rc;
     i = j;
   }
@@ -1488,6 +1550,7 @@ static scsfm_pair_desc one_desc(const T* tgt_img, const T* ref_img, const T* tgt
   d.hint = nullptr;
   d.depth_shift = 0;
   d.g_tgt_img = nullptr; d.g_ref_img = nullptr;
+  d.smooth_ws = nullptr; d.smooth_edge = nullptr; d.smooth_out = nullptr; d.smooth_total = nullptr;
   return d;
 }
 
@@ -1545,6 +1608,11 @@ size_t scsfm_pair_ws_bytes(int B, int H, int W) {
   int scsfm_pairs_fwd_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,          \
                             double w_photo, double w_geom, void* stream) {                                            \
     return scsfm::pairs_fwd<T>(n, d, B, H, W, K, flags, w_photo, w_geom, stream);                                     \
+  }                                                                                                                   \
+  int scsfm_pairs_fwd_step_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,     \
+                                 double w_photo, double w_smooth, double w_geom, T* step_out, void* stream) {         \
+    if (!step_out) return SCSFM_ERR_ARG;                                                                              \
+    return scsfm::pairs_fwd<T>(n, d, B, H, W, K, flags, w_photo, w_geom, stream, step_out, w_smooth);                 \
   }                                                                                                                   \
   int scsfm_pairs_bwd_##SUF(int n, const scsfm_pair_desc* d, int B, int H, int W, const T* K, unsigned flags,          \
                             void* scratch, const T* g_photo, const T* g_geom, void* stream) {                         \

@@ -13,6 +13,7 @@
 // the forward and once per direction in the backward (the left / upper edge of a pixel is the
 // previous lane's / row's right / lower edge).
 #include "scsfm_common.h"
+#include "scsfm_smooth_math.h"
 
 namespace scsfm {
 
@@ -68,10 +69,6 @@ struct SmoothBatch {
 };
 
 template <typename T>
-struct Px {  // depth and colours of one pixel
-  T d, c0, c1, c2;
-};
-template <typename T>
 __device__ __forceinline__ Px<T> load_px(const T* __restrict__ depth, const T* __restrict__ img, unsigned plane, unsigned p) {
   Px<T> r;
   const unsigned off = p * unsigned(sizeof(T));
@@ -84,19 +81,6 @@ __device__ __forceinline__ Px<T> shfl_down_px(const Px<T>& v) {
   r.d = __shfl_down(v.d, 1); r.c0 = __shfl_down(v.c0, 1); r.c1 = __shfl_down(v.c1, 1); r.c2 = __shfl_down(v.c2, 1);
   return r;
 }
-// exp(-mean_c |I(p) - I(q)|), loss_functions.py:148-152
-template <typename T>
-__device__ __forceinline__ T edge_weight(const Px<T>& a, const Px<T>& b) {
-  return t_exp_weight((t_abs(a.c0 - b.c0) + t_abs(a.c1 - b.c1) + t_abs(a.c2 - b.c2)) * T(-1.0 / 3.0));
-}
-
-template <typename T>
-__device__ __forceinline__ Px<T> lane_right_px(const Px<T>& v) {
-  Px<T> r;
-  r.d = lane_right(v.d); r.c0 = lane_right(v.c0); r.c1 = lane_right(v.c1); r.c2 = lane_right(v.c2);
-  return r;
-}
-
 // Forward.  A wave covers 64 columns of which it owns 62 (lanes 0 and 63 are halo: they only supply the left / right
 // neighbour) and a thread walks a column strip of kSmFwdRows rows plus the row above and the row below it, so every
 // pixel value is loaded ~1.3 times (round 1: 2.5 times -- the right neighbours were loaded instead of taken from

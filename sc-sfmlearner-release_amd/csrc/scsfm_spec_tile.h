@@ -9,6 +9,7 @@
 #pragma once
 #include "scsfm_geom.h"
 #include "scsfm_ssim.h"
+#include "scsfm_smooth_math.h"
 #ifdef SCSFM_WITH_MARCH  // tuning / test builds (-Ivariants/src): the staged-forward variant's tap reader
 #include "scsfm_stagefwd_taps.h"
 #endif
@@ -30,11 +31,27 @@ __device__ __forceinline__ void sched_fence() {
 #define SCSFM_STAGE_TAPS 1
 #endif
 
+// The smooth loss of a tile's target frame (scsfm_pair_desc::smooth_ws): the strip's part of the three sums and of the
+// edge plane (scsfm_smooth_math.h), then one record {sum D, Sx, Sy} per WAVE: pa.sm_partials[(tile * waves + wave) * 3 ..].
+template <typename T, int STRIP>
+__device__ __forceinline__ void smooth_tile_part(const PairArgs<T>& pa, const Px<T> (&row)[STRIP], const Px<T>& up, const Px<T>& dn,
+                                                 int px, int py0, bool in_x, const bool (&own_row)[STRIP], T icx, T icy, int H,
+                                                 int W, int b, unsigned plane, int wave, int lane, size_t tile) {
+  T sm[3] = {T(0), T(0), T(0)};
+  smooth_strip<T, STRIP>(row, up, dn, px, py0, in_x, own_row, icx, icy, H, W, pa.sm_edge ? pa.sm_edge + (size_t)b * plane : nullptr, sm);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sm[i] = wave_sum_last(sm[i]);
+  if (lane == kWave - 1) {
+    double* o = pa.sm_partials + 3 * (tile * (kThreads / kWave) + wave);
+    o[0] = double(sm[0]); o[1] = double(sm[1]); o[2] = double(sm[2]);
+  }
+}
+
 template <typename T, bool kSsim, bool kScaled, unsigned kFlags, bool kStageFwd = false>
 // (kSpec: always true here -- the backward's own tiled pass is photo_tile in scsfm_pair.hip)
 __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, const PairBatch<T>& pb, int B, int H,
                                            int W, unsigned flags_arg, const T* __restrict__ g_photo,
-                                           const T* __restrict__ g_geom, T r_hint) {
+                                           const T* __restrict__ g_geom, T r_hint, T sm_icx = T(0), T sm_icy = T(0)) {
   constexpr bool kSpec = true;  // (the body is shared history with the backward's tiled pass: its !kSpec branches are dead here)
   const unsigned flags = kFlags == kRuntimeFlags ? flags_arg : kFlags;
   const int pair = blk.z / B, b = blk.z - pair * B;
@@ -102,6 +119,12 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
   T acc_g = T(0), acc_m = T(0);  // kSpec: forward sums over the pixels this block owns
   int bx0 = 1 << 30, bx1 = -(1 << 30), by0 = 1 << 30, by1 = -(1 << 30);
   __shared__ int sBox[kSpec ? kThreads / kWave : 1][4];
+  // fixed-point scatter cells: the bound of what this tile can add to one of them (scsfm_geom.h: win_units_of)
+  constexpr bool kFixed = sizeof(typename WinCell<T>::type) == 4 && sizeof(T) == 4;
+  __shared__ float sU[kThreads / kWave];
+  float ub = 0.0f;
+  // |dL/d diff_depth| <= |r| m + [mask] a m sum_c blend_c <= (|r| + 3) m; times 2 for d diff_depth / d D_p = 2 Z / (Z + D_p)^2
+  const float ub_coef = 2.0f * (float(t_abs(r_hint)) + (with_mask ? 3.0f : 0.0f));
   V2 cen[kSsim ? 1 : STRIP][kSsim ? 1 : 3];
   // kSpec: dL/d(warped colour c) of the owned pixels waits for the geometry tail -- parked in the LDS tile of
   // colour c, which is dead by the time that gradient exists (every thread only touches its own slots); in
@@ -147,6 +170,30 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
   #pragma unroll
       for (int c = 0; c < 3; ++c) rin_t[c] = ld_plane(tgtP, c, off);
     }
+#ifndef SCSFM_SMOOTH_AT  // tuning knob: where the tile evaluates its target frame's smooth loss: 0 = in front of the warp
+#define SCSFM_SMOOTH_AT 1  // phase (values in registers, two more rows loaded), 1 = behind the flush (everything re-read)
+#endif
+#if SCSFM_SMOOTH_AT == 0
+    if (pa.sm_partials != nullptr) {
+      Px<T> row[STRIP], up, dn;
+      bool own_row[STRIP];
+  #pragma unroll
+      for (int k = 0; k < STRIP; ++k) {
+        row[k].d = in_d[k]; row[k].c0 = in_t[k][0]; row[k].c1 = in_t[k][1]; row[k].c2 = in_t[k][2];
+        const int ly = strip * STRIP + k;
+        own_row[k] = ly >= 1 && ly <= TH - 2;
+      }
+      {
+        const int vu = t_clampi(py0 - 1, 0, H - 1), vd = t_clampi(py0 + STRIP, 0, H - 1);
+        const unsigned ou = (unsigned(vu) * unsigned(W) + unsigned(u)) * unsigned(sizeof(T));
+        const unsigned od = (unsigned(vd) * unsigned(W) + unsigned(u)) * unsigned(sizeof(T));
+        up.d = tgt_depth.at(u, vu, ou); up.c0 = ld_plane(tgtP, 0, ou); up.c1 = ld_plane(tgtP, 1, ou); up.c2 = ld_plane(tgtP, 2, ou);
+        dn.d = tgt_depth.at(u, vd, od); dn.c0 = ld_plane(tgtP, 0, od); dn.c1 = ld_plane(tgtP, 1, od); dn.c2 = ld_plane(tgtP, 2, od);
+      }
+      smooth_tile_part<T, STRIP>(pa, row, up, dn, px, py0, in_x, own_row, sm_icx, sm_icy, H, W, b, plane, strip, col,
+                                 (size_t)(b * nby + blk.y) * nbx + blk.x);
+    }
+#endif
     // ---- phase 1a ------------------------------------------------------------------------------
     // SCSFM_W_GROUP pixels' gathers are in flight together (tools/march_timing.py: with one pixel after the other this
     // phase took 12,400 of a tile's 48,000 cycles, a third of it vector instructions).  2 since the image loads are
@@ -182,7 +229,8 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
           if constexpr (kSsim) sXY[c][lrow + k + 1][col + 1] = xy[c]; else cen[k][c] = xy[c];
         }
         const T Dp = bilerp_rows(td[j], s);
-        const T ddk = clamp01(t_abs(s.Z - Dp) * t_rcp(s.Z + Dp));
+        const T isum = t_rcp(s.Z + Dp);
+        const T ddk = clamp01(t_abs(s.Z - Dp) * isum);
         mq[k] = inimg ? pixel_mask(s, with_auto, xy, in_r[k]) : T(0);
         coef[k] = a * mq[k] * (with_mask ? (T(1) - ddk) : T(1));
         bsum[k] = T(0);
@@ -192,6 +240,8 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
             if (mq[k] != T(0)) {  // this pixel will scatter: where its north-west tap lies
               bx0 = s.xa < bx0 ? s.xa : bx0; bx1 = s.xa > bx1 ? s.xa : bx1;
               by0 = s.ya < by0 ? s.ya : by0; by1 = s.ya > by1 ? s.ya : by1;
+              // ... and at most how much (NaN-safe: min returns the cap)
+              if constexpr (kFixed) ub += t_min(float(ub_coef * float(s.Z) * float(isum) * float(isum)), kFixCap);
             }
           }
         }
@@ -204,6 +254,10 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
         bx0 = a0 < bx0 ? a0 : bx0; bx1 = a1 > bx1 ? a1 : bx1; by0 = c0 < by0 ? c0 : by0; by1 = c1 > by1 ? c1 : by1;
       }
       if (col == 0) { sBox[strip][0] = bx0; sBox[strip][1] = bx1; sBox[strip][2] = by0; sBox[strip][3] = by1; }
+      if constexpr (kFixed) {
+        ub = wave_sum_last(ub);
+        if (col == kWave - 1) sU[strip] = ub;
+      }
     }
     STAMP(1);
     // ---- phase 1b: ring ------------------------------------------------------------------------
@@ -230,6 +284,7 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
   // (the wide window needs the lean layout -- its extension rows are the staging regions -- and 32-bit cells)
   constexpr bool kWideOk = SCSFM_WIDE_WINDOW && SCSFM_LEAN_LDS && SCSFM_STAGE_TAPS && kSpec && kSsim && sizeof(T) == 4 && TH == kTileH;
   int wrows = WH;
+  float fix_scale = kFixScale, fix_inv = kFixInv;  // (fixed-point cells only)
   auto scatter_box = [&]() {
     int x0 = sBox[0][0], x1 = sBox[0][1], y0 = sBox[0][2], y1 = sBox[0][3];
 #pragma unroll
@@ -244,13 +299,13 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     wx0 = ex <= WW ? x0 - (WW - ex) / 2 : (x0 + x1 + 1) / 2 - WW / 2;
     wy0 = ey <= wrows ? y0 - (wrows - ey) / 2 : (y0 + y1 + 1) / 2 - wrows / 2;
     cx0 = x0 - wx0; cx1 = x1 + 1 - wx0; cy0 = y0 - wy0; cy1 = y1 + 1 - wy0;
-    // A tile whose taps all land on fewer than kCompressiveCells cells (the 868 pixels of a tile on < 128 texels: an areal
-    // compression of about 7 or more; a cell wraps from 32 near-cap pixels) could pile enough near-cap terms on one
-    // fixed-point cell to wrap it (+-2048 units:
-    // scsfm_geom.h; reachable with a scene scaled down a hundredfold and a forward motion of several depths -- tests).
-    // Such a tile does without the window: it is moved out of every tap's reach, so all of them take the direct fp32
-    // atomics and the flush finds an empty region (cx0 + wx0, what the staging uses, is unchanged).
-    if (sizeof(Cell) == 4 && ex * ey < kCompressiveCells) { wx0 -= 1 << 28; cx0 += 1 << 28; cx1 += 1 << 28; }
+    // the unit of the window's cells follows from the tile's bound (every thread evaluates the same four values)
+    if constexpr (kFixed) {
+      float U = sU[0];
+#pragma unroll
+      for (int w = 1; w < kThreads / kWave; ++w) U += sU[w];
+      win_units_of(U, fix_scale, fix_inv);
+    }
   };
   // kStage (fp32 + SSIM): the texels the geometry tail samples -- the reference view's colours and depth around
   // where the tile lands -- are staged in LDS at the start of the tail: the colour planes behind the parked
@@ -458,10 +513,10 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
       if constexpr (kStage) {
         const GeomTaps<T> f = geom_fetch<kStageRows, !kLean>(bc, px, py, d_own[k], refP, ref_depth, H, W, flags, staged);
         gd[k] = geom_consume<T, Cell, WW, WH>(bc, f, px, py, d_own[k], gI, gdd[k], H, W, flags, win, wx0, wy0, g_scatter, acc, ww,
-                                              T(1), ovf);
+                                              kFixed ? T(fix_scale) : T(1), ovf);
       } else {
         gd[k] = geom_pixel<T, Cell, WW, WH>(bc, px, py, d_own[k], gI, gdd[k], ref_img, ref_depth, plane, H, W, flags, win, wx0,
-                                      wy0, g_scatter, acc, T(1), ovf);
+                                      wy0, g_scatter, acc, kFixed ? T(fix_scale) : T(1), ovf);
       }
     }
     // A barrier waits for every outstanding global store / atomic of the wave, so everything that writes to
@@ -479,8 +534,47 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
         st_at(g_dense, (unsigned(py) * unsigned(W) + unsigned(px)) * unsigned(sizeof(T)), gd[k]);
     }
     if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5)))
-      flush_scatter_region<T, Cell, WW, WH>(win, wx0, wy0, cx0, cy0, cx1, cy1, g_scatter, W, ww);
+      flush_scatter_region<T, Cell, WW, WH>(win, wx0, wy0, cx0, cy0, cx1, cy1, g_scatter, W, ww, kFixed ? T(fix_inv) : T(1));
     STAMP(8);
+#if SCSFM_SMOOTH_AT == 1
+    // ---- the target frame's smooth loss (loss_functions.py:133-152), for the pair that carries it (uniform) ----------
+    // Behind everything else: nothing of the tile is live any more, so the strip and the rows above and below it are
+    // read again (L2: the tile streamed them a moment ago) and the arithmetic overlaps the other resident workgroups'
+    // phases instead of sitting in front of this tile's first gathers (in front of the warp phase: +26 us per launch at
+    // configs[1], measured; here: see profiles/r06_kernel_experiments.json).  No barrier: every wave leaves its own record.
+    if (pa.sm_partials != nullptr) {
+      // (the row offsets below are the expressions of phase 0: unless the first row is made opaque here, the compiler
+      // keeps phase 0's values alive across the whole tile -- 13 registers spilled)
+      int py0e = py0, pxe = px;
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+s"(py0e));
+      asm volatile("" : "+v"(pxe));
+#endif
+      const int u = reflect_index(pxe, W);
+      Px<T> row[STRIP], up, dn;
+      bool own_row[STRIP];
+      auto load = [&](int y) {
+        const int v = t_clampi(y, 0, H - 1);
+        const unsigned off = (unsigned(v) * unsigned(W) + unsigned(u)) * unsigned(sizeof(T));
+        Px<T> q;
+        q.d = tgt_depth.at(u, v, off); q.c0 = ld_plane(tgtP, 0, off); q.c1 = ld_plane(tgtP, 1, off); q.c2 = ld_plane(tgtP, 2, off);
+        return q;
+      };
+      up = load(py0e - 1);
+#pragma unroll
+      for (int k = 0; k < STRIP; ++k) {
+        // (rows of the strip as the warp phase read them: reflected -- only in-image rows are owned or enter an edge)
+        const int v = reflect_index(py0e + k, H);
+        const unsigned off = (unsigned(v) * unsigned(W) + unsigned(u)) * unsigned(sizeof(T));
+        row[k].d = tgt_depth.at(u, v, off); row[k].c0 = ld_plane(tgtP, 0, off); row[k].c1 = ld_plane(tgtP, 1, off); row[k].c2 = ld_plane(tgtP, 2, off);
+        const int ly = strip * STRIP + k;
+        own_row[k] = ly >= 1 && ly <= TH - 2;
+      }
+      dn = load(py0e + STRIP);
+      smooth_tile_part<T, STRIP>(pa, row, up, dn, pxe, py0e, in_x, own_row, sm_icx, sm_icy, H, W, b, plane, strip, col,
+                                 (size_t)(b * nby + blk.y) * nbx + blk.x);
+    }
+#endif
   }
 }
 

@@ -412,7 +412,7 @@ static int pose_bwd(int B, const T* vec, int mode, const T* g_mat, T* g_vec, voi
 
 extern "C" {
 
-int scsfm_abi_version(void) { return 8; }
+int scsfm_abi_version(void) { return 9; }
 
 #ifndef SCSFM_SOURCE_ID
 #define SCSFM_SOURCE_ID "unknown"

@@ -23,7 +23,7 @@ HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "scsfm_
 # SCSFM_HIP_LIB points at a library built elsewhere (tuning variants, a system-wide install)
 LIB_PATH = os.environ.get("SCSFM_HIP_LIB") or os.path.join(HERE, "libscsfm_hip.so")
 
-ABI_VERSION = 8  # include/scsfm_hip.h
+ABI_VERSION = 9  # include/scsfm_hip.h
 
 _CTYPES = {"int": ctypes.c_int, "unsigned": ctypes.c_uint, "size_t": ctypes.c_size_t, "double": ctypes.c_double}
 _DECL = re.compile(r"^(int|size_t)\s+(scsfm_\w+)\s*\(([^)]*)\)\s*;", re.M | re.S)

@@ -321,7 +321,8 @@ class PairDesc(_ct.Structure):
     """scsfm_pair_desc of include/scsfm_hip.h."""
     _fields_ = [(n, _ct.c_void_p) for n in ("tgt_img", "ref_img", "tgt_depth", "ref_depth", "pose", "ws", "out",
                                             "g_tgt_depth", "g_ref_depth", "g_pose", "gbuf", "total", "hint")] + \
-               [("depth_shift", _ct.c_int), ("g_tgt_img", _ct.c_void_p), ("g_ref_img", _ct.c_void_p)]
+               [("depth_shift", _ct.c_int), ("g_tgt_img", _ct.c_void_p), ("g_ref_img", _ct.c_void_p)] + \
+               [(n, _ct.c_void_p) for n in ("smooth_ws", "smooth_edge", "smooth_out", "smooth_total")]
 
 
 def depth_shift(shape, B, H, W):
@@ -375,8 +376,18 @@ class WindowOverflow(RuntimeError):
     """A fixed-point cell of the speculative forward's scatter window wrapped (SCSFM_CHECK_WINDOW=1 runs only)."""
 
 
+def smooth_rides_along(flags, tgt_img, tgt_depths, ref_depths, hint):
+    """Can the speculative forward carry the smooth loss of the step's frames (scsfm_pair_desc::smooth_ws)?  It needs a
+    speculative launch (``hint`` with a non-zero photo weight) and every frame's scale-0 depth map at full resolution --
+    each frame is then the target of a pair-direction at depth_shift 0."""
+    if hint is None or float(hint[0]) == 0.0:
+        return False
+    B, _, H, W = tgt_img.shape
+    return all(tuple(m.shape) == (B, 1, H, W) for m in [tgt_depths[0]] + [r[0] for r in ref_depths])
+
+
 def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, group=None,
-                       hint=None, ws=None, hint_dev=None, check_window=False):
+                       hint=None, ws=None, hint_dev=None, check_window=False, smooth=False, keep_edges=True, step=None):
     """All pair-directions of loss_functions.py:56-90 in ONE call into the library.  ``tgt_depths[s]``
     and ``ref_depths[i][s]`` are full-resolution maps or, for a coarser scale, [B, 1, H >> k, W >> k] maps that the
     kernels read through the nearest up-sampling's index map (`depth_shift`).  Returns (photo, geom, outs [n_pairs, 8], ws)
@@ -395,7 +406,15 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
 
     ``group``: a torch.distributed process group -> exact data-parallel mode: the three raw sums of
     every pair are all-reduced (one [n_pairs, 3] collective) and the masked means are re-evaluated on
-    the global sums, so every rank holds the losses of the concatenated batch."""
+    the global sums, so every rank holds the losses of the concatenated batch.
+
+    ``smooth`` (only where smooth_rides_along() holds): the speculative forward also evaluates compute_smooth_loss
+    (loss_functions.py:132-159) of the frames [tgt, refs...] at scale 0 -- each frame in the tile of the first
+    pair-direction whose TARGET it is -- and the call returns two more values: the smooth loss (the sum over the frames)
+    and the smooth workspace ``sws``, laid out exactly as smooth_multi_fwd leaves it (smooth_multi_bwd and
+    photo_geometry_bwd(smooth=...) take it from there; ``keep_edges`` as there).  ``step`` = (w_photo, w_smooth, w_geom)
+    with ``smooth``: a seventh value, tensor[4] = {w_photo photo + w_smooth smooth + w_geom geometry, photo, smooth,
+    geometry}, formed by the same finalize launch (scsfm_pairs_fwd_step; not in the exact data-parallel mode)."""
     B, _, H, W = tgt_img.shape
     pairs = _pair_list(tgt_img, ref_imgs, tgt_depths, ref_depths, poses, poses_inv)
     n = len(pairs)
@@ -420,16 +439,41 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         assert hint_dev.dtype == torch.float64 and hint_dev.numel() == 2 and hint_dev.device == tgt_img.device
         descs[0].hint = hint_dev.data_ptr()
     wp, op, esz = ws.data_ptr(), outs.data_ptr(), outs.element_size() * 8
-    for j, (ti, ri, dt, dr, po, _, _) in enumerate(pairs):
+    sws = souts = step_out = None
+    if smooth:
+        assert spec and smooth_rides_along(flags, tgt_img, tgt_depths, ref_depths, hint), "smooth=True needs a speculative forward on full-resolution maps"
+        assert step is None or group is None, "the step total is not formed in the exact data-parallel mode"
+        nf = 1 + len(ref_imgs)
+        sw_bytes = _sizes(lib, B, H, W)[2]
+        plane_bytes = ((B * H * W * tgt_img.element_size() + 255) // 256) * 256 if keep_edges else 0
+        sws = torch.empty(nf * (sw_bytes + plane_bytes), dtype=torch.uint8, device=tgt_img.device)
+        souts = torch.empty(nf + 1, dtype=tgt_img.dtype, device=tgt_img.device)  # one loss per frame, then their sum
+        descs[0].smooth_total = souts.data_ptr() + nf * souts.element_size()
+    seen = set()
+    for j, (ti, ri, dt, dr, po, kt, _) in enumerate(pairs):
         d = descs[j]
         d.tgt_img, d.ref_img, d.tgt_depth, d.ref_depth, d.pose = ti.data_ptr(), ri.data_ptr(), dt.data_ptr(), \
             dr.data_ptr(), po.data_ptr()
         d.ws, d.out = wp + j * stride, op + j * esz
         d.gbuf = wp + j * stride + ws_bytes if spec else None
         d.depth_shift = shifts[j]
-    lib.call(f"scsfm_pairs_fwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K),
-             flags | (DEBUG_CHECK_WINDOW if check_window else 0),
-             float(hint[0]) if spec else 0.0, float(hint[1]) if spec else 0.0, _stream(tgt_img))
+        if smooth and kt[-1] == 0 and kt not in seen:  # the first pair-direction whose target is this frame at scale 0
+            seen.add(kt)
+            f = 0 if kt[0] == "t" else 1 + kt[1]  # frame order of compute_smooth_loss: target, then the references
+            d.smooth_ws = sws.data_ptr() + f * sw_bytes
+            d.smooth_edge = sws.data_ptr() + nf * sw_bytes + f * plane_bytes if keep_edges else None
+            d.smooth_out = souts.data_ptr() + f * souts.element_size()
+    if smooth:
+        assert len(seen) == nf
+    if smooth and step is not None:
+        step_out = torch.empty(4, dtype=tgt_img.dtype, device=tgt_img.device)
+        lib.call(f"scsfm_pairs_fwd_step_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K),
+                 flags | (DEBUG_CHECK_WINDOW if check_window else 0), float(step[0]), float(step[1]), float(step[2]),
+                 _p(step_out), _stream(tgt_img))
+    else:
+        lib.call(f"scsfm_pairs_fwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K),
+                 flags | (DEBUG_CHECK_WINDOW if check_window else 0),
+                 float(hint[0]) if spec else 0.0, float(hint[1]) if spec else 0.0, _stream(tgt_img))
     if check_window:
         wrapped = int(outs[:n, 7].sum().item())  # (synchronises: a debugging mode)
         if wrapped:
@@ -443,13 +487,14 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         outs[:n, 2:5] = sums
         for j in range(n):
             pair_refinalize(lib, (B, H, W), ws[j * stride:j * stride + ws_bytes], outs[j])
+    extra = () if not smooth else ((souts[nf], sws) if step is None else (souts[nf], sws, step_out))
     if flags & 16384:  # SCSFM_DEBUG_KERNEL_ONLY (bench.py): nothing was finalised
-        return None, None, outs[:n], ws
+        return (None, None, outs[:n], ws) + extra
     if group is not None:
         tot = outs[:n, :2].sum(dim=0)  # the re-finalised losses
-        return tot[0], tot[1], outs[:n], ws
+        return (tot[0], tot[1], outs[:n], ws) + extra
     # plain sums over refs, scales and directions (loss_functions.py:89-90), left in the last row by the library
-    return outs[n, 0], outs[n, 1], outs[:n], ws
+    return (outs[n, 0], outs[n, 1], outs[:n], ws) + extra
 
 
 def window_overflows(lib, ws, n_pairs, B, H, W, spec=True):

@@ -53,3 +53,22 @@ def check_window():
     call."""
     import os
     return os.environ.get("SCSFM_CHECK_WINDOW") == "1"
+
+
+_smooth_rides = None
+
+
+def smooth_rides_along():
+    """Does the speculative forward of compute_photo_and_geometry_loss also evaluate the smooth loss of its frames (round 6:
+    scsfm_pair_desc::smooth_ws; the compute_smooth_loss call that follows then finds its result waiting)?  Default on;
+    SCSFM_SMOOTH_RIDE=0 (read once) or set_smooth_rides_along(False) restore the stand-alone smooth forward."""
+    global _smooth_rides
+    if _smooth_rides is None:
+        import os
+        _smooth_rides = os.environ.get("SCSFM_SMOOTH_RIDE", "1") != "0"
+    return _smooth_rides
+
+
+def set_smooth_rides_along(on):
+    global _smooth_rides
+    _smooth_rides = bool(on)

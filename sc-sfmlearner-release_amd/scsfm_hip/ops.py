@@ -6,6 +6,8 @@ libscsfm_hip.so or a CPU tensor raises.  Host-side there is no synchronisation: 
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import _lib, capi
@@ -31,6 +33,41 @@ def _scalar(g, like):
 # ------------------------------------------------------------------------------------------------
 # compute_photo_and_geometry_loss: all refs x scales x both directions behind one autograd node
 # ------------------------------------------------------------------------------------------------
+class _SmoothStash:
+    """What the speculative forward of compute_photo_and_geometry_loss left for the compute_smooth_loss call that
+    train.py:262-266 makes next on the SAME frames: the loss, and the smooth workspace the backward needs.  Keyed on the
+    identity of the tensor OBJECTS (weak references: a new tensor at a recycled address is another object) and their
+    version counters (an in-place write in between invalidates the entry); consumed by the first matching call, replaced
+    by the next forward.  A miss costs nothing but the stand-alone smooth forward."""
+    slot = None
+
+    @staticmethod
+    def key(depths, imgs):
+        return [(weakref.ref(t), t._version) for t in list(depths) + list(imgs)]
+
+    @classmethod
+    def put(cls, depths, imgs, loss, sws, keep_edges):
+        cls.slot = (cls.key(depths, imgs), loss, sws, keep_edges, _stream_id(imgs[0]))
+
+    @classmethod
+    def take(cls, depths, imgs, keep_edges):
+        slot, cls.slot = cls.slot, None
+        if slot is None:
+            return None
+        keys, loss, sws, kept, stream = slot
+        ts = list(depths) + list(imgs)
+        if len(keys) != len(ts) or (keep_edges and not kept) or stream != _stream_id(imgs[0]):
+            return None
+        for (ref, ver), t in zip(keys, ts):
+            if ref() is not t or t._version != ver:
+                return None
+        return loss, sws
+
+
+def _stream_id(t):
+    return capi._stream(t)
+
+
 class PhotoGeometryLoss(torch.autograd.Function):
     """forward(flags, n_ref, n_scales, tgt_img, K, *ref_imgs, *tgt_depths, *ref_depths, *poses,
     *poses_inv) -> (photo_loss, geometry_loss)
@@ -54,6 +91,8 @@ class PhotoGeometryLoss(torch.autograd.Function):
     def forward(ctx, flags, n_ref, n_scales, tgt_img, K, *rest):
         from . import config as _config, dist as _dist
         lib = _lib.get()
+        orig_ref_imgs, orig_depths, orig_ref_depths, _, _, _ = PhotoGeometryLoss._split(list(rest), n_ref, n_scales)
+        orig_tgt_img = tgt_img
         rest = [_c(t) for t in rest]
         tgt_img, K = _c(tgt_img), _c(K)
         _need_cuda(tgt_img, K, *rest)
@@ -62,9 +101,16 @@ class PhotoGeometryLoss(torch.autograd.Function):
         hint = _config.weight_hint() if any(ctx.needs_input_grad) else None
         # the pair the kernels speculate on lives on the device: every backward leaves the upstream gradients it saw there
         hint_dev = _config.hint_tensor(tgt_img.device) if hint is not None else None
-        photo, geom, _, ws = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
-                                                     poses_inv, group=_dist.exact_group(), hint=hint, hint_dev=hint_dev,
-                                                     check_window=hint is not None and _config.check_window())
+        # the smooth loss of the same frames (the call train.py:262-266 makes next) rides in the speculative tiles and
+        # waits in the stash: identity of the ORIGINAL tensor objects, which is what compute_smooth_loss will be handed
+        ride = _config.smooth_rides_along() and capi.smooth_rides_along(flags, tgt_img, tgt_depths, ref_depths, hint)
+        res = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
+                                      poses_inv, group=_dist.exact_group(), hint=hint, hint_dev=hint_dev,
+                                      check_window=hint is not None and _config.check_window(), smooth=ride)
+        photo, geom, _, ws = res[:4]
+        if ride:
+            frames = [orig_depths[0]] + [orig_ref_depths[i][0] for i in range(n_ref)]
+            _SmoothStash.put(frames, [orig_tgt_img] + orig_ref_imgs, res[4], res[5], True)
         ctx.flags, ctx.n_ref, ctx.n_scales = flags, n_ref, n_scales
         ctx.hint_dev = hint_dev
         ctx.save_for_backward(tgt_img, K, *rest, ws)
@@ -130,10 +176,14 @@ class SmoothLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, n, *rest):
         lib = _lib.get()
+        orig = list(rest)
         rest = [_c(t) for t in rest]
         _need_cuda(*rest)
         depths, imgs = rest[:n], rest[n:]
-        loss, ws = capi.smooth_multi_fwd(lib, depths, imgs, keep_edges=any(ctx.needs_input_grad[1:1 + n]))
+        keep = any(ctx.needs_input_grad[1:1 + n])
+        # (autograd hands forward() the caller's tensor objects: the stash is keyed on them)
+        hit = _SmoothStash.take(orig[:n], orig[n:], keep)
+        loss, ws = hit if hit is not None else capi.smooth_multi_fwd(lib, depths, imgs, keep_edges=keep)
         ctx.n = n
         ctx.save_for_backward(*rest, ws)
         return loss
@@ -176,16 +226,26 @@ class StepLoss(torch.autograd.Function):
         ref_imgs, tgt_depths, ref_depths, poses, poses_inv, _ = PhotoGeometryLoss._split(rest, n_ref, n_scales)
         hint = (float(np.float32(w_photo)), float(np.float32(w_geom))) if (w_photo != 0 and any(ctx.needs_input_grad)) else None
         from . import config as _config
-        photo, geom, _, ws = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
-                                                     poses_inv, group=_dist.exact_group(), hint=hint,
-                                                     check_window=hint is not None and _config.check_window())
-        frames = [tgt_depths[0]] + [r[0] for r in ref_depths]
-        imgs = [tgt_img] + list(ref_imgs)
-        # (photo, geom) are elements 0 and 1 of one contiguous row -- the library's totals, or the exact mode's sums;
-        # the smooth forward's finalize launch also forms the weighted sum (no scsfm_step_total launch)
-        assert geom.data_ptr() == photo.data_ptr() + photo.element_size()
-        smooth, sws, out = capi.smooth_multi_fwd(lib, frames, imgs, keep_edges=any(ctx.needs_input_grad),
-                                                 step=(photo, w_photo, w_smooth, w_geom))
+        group = _dist.exact_group()
+        ride = group is None and _config.smooth_rides_along() and \
+            capi.smooth_rides_along(flags, tgt_img, tgt_depths, ref_depths, hint)
+        if ride:
+            # one launch sequence for the whole forward: the speculative tiles carry the frames' smooth loss and the
+            # finalize launch forms the weighted sum (scsfm_pairs_fwd_step)
+            photo, geom, _, ws, smooth, sws, out = capi.photo_geometry_fwd(
+                lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, hint=hint,
+                check_window=_config.check_window(), smooth=True, keep_edges=True, step=(w_photo, w_smooth, w_geom))
+        else:
+            photo, geom, _, ws = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
+                                                         poses_inv, group=group, hint=hint,
+                                                         check_window=hint is not None and _config.check_window())
+            frames = [tgt_depths[0]] + [r[0] for r in ref_depths]
+            imgs = [tgt_img] + list(ref_imgs)
+            # (photo, geom) are elements 0 and 1 of one contiguous row -- the library's totals, or the exact mode's sums;
+            # the smooth forward's finalize launch also forms the weighted sum (no scsfm_step_total launch)
+            assert geom.data_ptr() == photo.data_ptr() + photo.element_size()
+            smooth, sws, out = capi.smooth_multi_fwd(lib, frames, imgs, keep_edges=any(ctx.needs_input_grad),
+                                                     step=(photo, w_photo, w_smooth, w_geom))
         ctx.cfg = (flags, n_ref, n_scales, w_photo, w_smooth, w_geom)
         ctx.save_for_backward(tgt_img, K, *rest, ws, sws)
         loss, photo_o, smooth_o, geom_o = out[0], out[1], out[2], out[3]

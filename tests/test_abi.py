@@ -35,6 +35,8 @@ EXPECTED = {
     # ABI 8: the smooth loss's depth gradients added by the pair backward's combining pass
     "scsfm_pairs_bwd_smooth_f32", "scsfm_pairs_bwd_smooth_f64",
     "scsfm_smooth_multi_fwd_step_f32", "scsfm_smooth_multi_fwd_step_f64",
+    # ABI 9: the smooth loss riding in the speculative forward (scsfm_pair_desc::smooth_ws); the step total in its finalize launch
+    "scsfm_pairs_fwd_step_f32", "scsfm_pairs_fwd_step_f64",
 }
 
 

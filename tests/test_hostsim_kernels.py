@@ -518,9 +518,11 @@ def _compressive_case(B, scale, tz, seed=67):
 def test_compressive_warps_do_not_wrap_the_fixed_point_window_fp32(lib, B, scale, tz, w_geom, hint):
     """Round-4 review: the fixed-point scatter cells (+-2048 units) wrap SILENTLY if more than 32 near-cap pixels of one
     tile pile on one reference texel.  Reachable (second half of the cases; errors of 70 .. 145 % of the map's scale were
-    measured before round 5).  Now a tile whose scatter footprint covers fewer than kCompressiveCells cells bypasses the
-    window, and debug launches (SCSFM_DEBUG_CHECK_WINDOW) count wraps exactly: here the count must be zero and
-    dL/d ref_depth must match the fp64 oracle."""
+    measured before round 5).  Round 5 let tiles with a small scatter footprint bypass the window (a heuristic); round 6
+    derives the unit of a tile's cells from an upper bound of everything the tile can add to one of them
+    (scsfm_geom.h: win_units_of), so that no cell can wrap whatever the warp does, and the fallback pass stages in floating
+    cells.  Debug launches (SCSFM_DEBUG_CHECK_WINDOW) count wraps exactly: the count must be zero and dL/d ref_depth must
+    match the fp64 oracle."""
     ti, K, ris, tds, rds, ps, pis = _compressive_case(B, scale, tz)
     c = lambda x: x.double()
     td64, rd64 = [leaf(c(tds[0]))], [[leaf(c(rds[0][0]))]]
@@ -535,9 +537,49 @@ def test_compressive_warps_do_not_wrap_the_fixed_point_window_fp32(lib, B, scale
     assert _rel(g_rd[0][0].double(), rd64[0][0].grad) < 1e-4 and _rel(g_td[0].double(), td64[0].grad) < 1e-4
 
 
+def _nonuniform_case(B=2, seed=71):
+    """Round-5 review: a NON-uniform compression inside a large footprint, which the bounding-box heuristic of round 5
+    could not see.  Forward motion tz; the left half of every row is very near (depth << tz: those pixels collapse onto
+    a few texels around the principal point, their unscaled scatter terms 2 Z / (Z + D_p)^2 ~ 25 each), the right half is
+    far (depth >> tz: they stay where they are and spread over hundreds of cells).  Photo-only upstream gradient: all
+    terms of one sign."""
+    H, W = 72, 100
+    d = synth.make_batch(B, H, W, n_ref=1, seed=seed, depth="smooth")
+    g = torch.Generator().manual_seed(9)
+    tz = 0.06
+    near = 0.002 + 0.002 * torch.rand(B, 1, H, W, generator=g)
+    far = 5.0 + 2.0 * torch.rand(B, 1, H, W, generator=g)
+    left = (torch.arange(W) % 2 == 0).view(1, 1, 1, W)  # alternate columns: every tile holds both kinds
+    tds = [torch.where(left, near, far).contiguous()]
+    rds = [[(0.004 + 0.004 * torch.rand(B, 1, H, W, generator=g)).contiguous()]]
+    p = torch.zeros(B, 6)
+    p[:, 2] = tz
+    return d["tgt_img"], d["intrinsics"], d["ref_imgs"], tds, rds, [p], [-p.clone()]
+
+
+@pytest.mark.parametrize("auto", [0, 1])
+def test_nonuniform_compression_inside_a_large_footprint_fp32(lib, auto):
+    ti, K, ris, tds, rds, ps, pis = _nonuniform_case()
+    c = lambda x: x.double()
+    td64, rd64 = [leaf(c(tds[0]))], [[leaf(c(rds[0][0]))]]
+    po, go = O.photo_and_geometry_loss(c(ti), [c(ris[0])], c(K), td64, rd64, [c(ps[0])], [c(pis[0])], 1, 1, 1, auto, "zeros")
+    po.backward()
+    fl = capi.make_flags(1, 1, auto, "zeros")
+    photo, geom, outs, ws = capi.photo_geometry_fwd(lib, fl, ti, K, ris, tds, rds, ps, pis, hint=(1.0, 0.0), check_window=True)
+    assert abs(float(photo) - float(po)) < 1e-5 and abs(float(geom) - float(go)) < 1e-5
+    g_td, g_rd, _, _ = capi.photo_geometry_bwd(lib, fl, ti, K, ris, tds, rds, ps, pis, ws, torch.tensor([1.0]),
+                                               torch.tensor([0.0]), check_window=True)
+    assert capi.window_overflows(lib, ws, 2, 2, 72, 100) == [0, 0]
+    # the case is what it claims to be: the terms piled on the busiest reference texel exceed a 2^-20 cell's range
+    unscaled = rd64[0][0].grad.abs().max() * 3 * float(outs[0, 4])
+    assert float(unscaled) > 2048, float(unscaled)
+    assert _rel(g_rd[0][0].double(), rd64[0][0].grad) < 1e-4 and _rel(g_td[0].double(), td64[0].grad) < 1e-4
+
+
 def test_the_wrap_detector_fires_without_the_guard():
-    """The same scaled scene on a build WITHOUT the compressive-tile guard (-DSCSFM_COMPRESSIVE_CELLS=0, its own
-    simulation library): cells wrap, dL/d ref_depth is off by multiples of 4096 units, and the debug launch says so --
+    """The same scaled scene on a build WITHOUT the per-tile bound of the cells' unit (-DSCSFM_WINDOW_BOUND=0, its own
+    simulation library: every tile counts in 2^-20 as before round 6): cells wrap, dL/d ref_depth is off by multiples of
+    4096 units, and the debug launch says so --
     capi.photo_geometry_fwd(check_window=True) raises WindowOverflow.  (A subprocess: the simulation's build flags are
     fixed at import.)"""
     import os
@@ -561,7 +603,7 @@ except capi.WindowOverflow as e:
     print("RAISED", n[0])
 """ % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
        os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sc-sfmlearner-release_amd"))
-    env = dict(os.environ, HOSTSIM_EXTRA="-DSCSFM_COMPRESSIVE_CELLS=0")
+    env = dict(os.environ, HOSTSIM_EXTRA="-DSCSFM_WINDOW_BOUND=0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "RAISED" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 

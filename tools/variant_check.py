@@ -60,6 +60,9 @@ def main():
         _, _, _, ws = capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, pp, pis, hint=(1.0, 0.5))
         fn = lambda: capi.photo_geometry_fwd(lib, fl | 16384, tgt, K, refs, tds, rds, pp, pis, hint=(1.0, 0.5), ws=ws)
         out["us"][depth] = [round(bench._event_time(fn, a.iters) * 1e6, 1) for _ in range(a.rounds)]
+        if hasattr(capi, "smooth_rides_along"):  # (round 6) ... with the frames' smooth loss riding in the tiles
+            fr = lambda: capi.photo_geometry_fwd(lib, fl | 16384, tgt, K, refs, tds, rds, pp, pis, hint=(1.0, 0.5), ws=ws, smooth=True)
+            out.setdefault("us_ride", {})[depth] = [round(bench._event_time(fr, a.iters) * 1e6, 1) for _ in range(a.rounds)]
         if a.extra or register is not None:
             # the smooth loss's forward over the step's frames; with texel planes registered it packs them on the way
             sm_frames, sm_imgs = tds + [r[0] for r in rds], [tgt] + list(refs)
