@@ -91,11 +91,14 @@ def hot_path_step_single_node(LF, x, flags):
 
 
 def pmc_traffic(args, n_pairs, lib_source_id):
-    """-> (HBM bytes per launch of the dominant kernel | None, why).  The bytes are QUOTED from the committed PMC passes
-    (profiles/pmc_latest.json: FETCH_SIZE + WRITE_SIZE in KiB per dispatch, collected in separate `rocprofv3 --pmc` runs
+    """-> ({"fetch_bytes", "write_bytes", ...} | None, why).  The bytes are QUOTED from the committed PMC passes
+    (profiles/pmc_latest.json: FETCH_SIZE and WRITE_SIZE in KiB per dispatch, collected in separate `rocprofv3 --pmc` runs
     of this very command -- tools/gpu_round.sh), and only for the workload AND the library they were collected on: the
     file records the source id of the library that ran (`_library_source_id`), and a loaded library with another id --
-    a later kernel change -- gets None instead of the old counters."""
+    a later kernel change -- gets None instead of the old counters.  The two counters are reported SEPARATELY, raw and
+    corrected with the calibration of profiles/r06_fetch_calibration.json (known-bytes kernels of tools/ubench/fetch_calib.hip
+    in this library's access widths under the same counters; MI355X_MICROARCH.md: FETCH_SIZE counts half the bytes of wide
+    streaming reads on gfx950)."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if not os.path.exists(path):
         return None, "no profiles/pmc_latest.json"
@@ -110,9 +113,40 @@ def pmc_traffic(args, n_pairs, lib_source_id):
         # the training-flags instantiation of the speculative forward (the template list grew over the rounds)
         keys = [n for n in d if n.startswith("scsfm::pair_fwd_spec_kernel<float, true, 7u") and n.endswith(f"|gz{gz}")]
         k = d[keys[0]]
-        return int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024), "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_round.sh on this library)"
+        out = {"fetch_bytes_raw": int(k["FETCH_SIZE"] * 1024), "write_bytes_raw": int(k["WRITE_SIZE"] * 1024)}
+        cal_path = os.path.join(ROOT, "profiles", "r06_fetch_calibration.json")
+        if os.path.exists(cal_path):
+            cal = json.load(open(cal_path)).get("kernels", {})
+            # the kernel's reads are 4-byte coalesced rows and 8-byte gathers, its writes 4-byte rows and float atomics
+            f = [v["FETCH_SIZE_over_known"] for n, v in cal.items() if ("read_kernel<unsigned int>" in n or "gather_b64" in n) and "FETCH_SIZE_over_known" in v]
+            w = [v["WRITE_SIZE_over_known"] for n, v in cal.items() if ("write_kernel<unsigned int>" in n or "atomic_f32" in n) and "WRITE_SIZE_over_known" in v]
+            if f and w:
+                out["fetch_counter_per_known_byte"] = round(sum(f) / len(f), 4)
+                out["write_counter_per_known_byte"] = round(sum(w) / len(w), 4)
+                out["fetch_bytes"] = int(out["fetch_bytes_raw"] / (sum(f) / len(f)))
+                out["write_bytes"] = int(out["write_bytes_raw"] / (sum(w) / len(w)))
+                out["calibration"] = "profiles/r06_fetch_calibration.json"
+        return out, "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_round.sh on this library): QUOTED, not measured in this run"
     except (KeyError, ValueError, IndexError, TypeError):
         return None, "profiles/pmc_latest.json has no entry for the dominant kernel"
+
+
+def issue_bound(lib_source_id, tiles, waves_per_tile=4, simds=1024):
+    """-> (issue_bound_us | None, detail): the launch time if the vector ALUs never idled = static issue units per
+    thread (profiles/issue_cost_latest.json, tools/issue_bound.py -- only for the library it was computed on) x waves per
+    SIMD per launch x the measured issue time of a unit."""
+    path = os.path.join(ROOT, "profiles", "issue_cost_latest.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "no profiles/issue_cost_latest.json (tools/issue_bound.py)"
+    if d.get("_library_source_id") != lib_source_id:
+        return None, f"issue cost is that of library {d.get('_library_source_id')}, the loaded one is {lib_source_id}: re-run tools/issue_bound.py"
+    waves_per_simd = tiles * waves_per_tile / simds
+    us = d["issue_units_per_thread"] * d["ns_per_unit_per_simd"] * waves_per_simd * 1e-3
+    return us, {"issue_units_per_thread": d["issue_units_per_thread"], "static_valu_instructions": d["static_valu_instructions"],
+                "waves_per_simd_per_launch": round(waves_per_simd, 2), "ns_per_unit": d["ns_per_unit_per_simd"],
+                "source": "profiles/issue_cost_latest.json (tools/issue_bound.py: static listing x issue weights measured with tools/ubench)"}
 
 
 def _event_time(fn, iters):
@@ -167,6 +201,12 @@ def time_kernels(x, flags, iters, n_ref):
         "smooth_fwd": lambda: capi.smooth_multi_fwd(lib, frames, imgs),
         "smooth_bwd": lambda: capi.smooth_multi_bwd(lib, frames, imgs, sws, one),
     }
+    if capi.smooth_rides_along(fl, tgt, tds, rds, hint):
+        # round 6: the forward as the product runs it -- the frames' smooth loss evaluated in the speculative tiles (no
+        # smooth_fwd launch in the step) -- and the dominant kernel alone in that mode
+        calls["pairs_fwd_spec_with_smooth"] = lambda: capi.photo_geometry_fwd(lib, fl, tgt, K, refs, tds, rds, ps, pis, hint=hint, smooth=True)
+        calls["spec_kernel_only_with_smooth"] = lambda: capi.photo_geometry_fwd(lib, fl | 16384, tgt, K, refs, tds, rds, ps, pis,
+                                                                                hint=hint, ws=ws_spec, smooth=True)
     return {k: _event_time(fn, iters) for k, fn in calls.items()}
 
 
@@ -257,12 +297,12 @@ def cpu_baseline(args, budget_s):
         variants.append((min(avail, 4 * cores), b_gpu, 0))
     variants = list(dict.fromkeys(variants))
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--impl", "reference" if kind == "reference" else "oracle",
-           "--variants", ",".join(f"{t}:{b}:{a}" for t, b, a in variants), "--seconds", str(budget_s),
+           "--variants", ",".join(f"{t}:{b}:{a}" for t, b, a in variants), "--seconds", str(budget_s), "--min-steps", "15",
            "--height", str(args.height), "--width", str(args.width), "--n-ref", str(args.n_ref), "--depth", args.depth,
            "--dataset", args.dataset]
     env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH",)}
     env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""  # host cores only
-    out = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=env, timeout=max(120.0, 20 * budget_s))
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=env, timeout=max(240.0, 20 * budget_s))
     if out.returncode != 0:
         raise RuntimeError("cpu baseline failed: " + out.stderr[-2000:])
     rows = json.loads(out.stdout.strip().split("\n")[-1])
@@ -270,10 +310,13 @@ def cpu_baseline(args, budget_s):
     n_px = head["batch"] * args.height * args.width
     return {"value": head["images_per_sec"], "unit": "images/s (loss path only, fwd+bwd)", "cores": head["threads"], "kind": kind,
             "sample": f"{'unmodified reference loss_functions.py' if kind == 'reference' else 'oracle (ATen CPU ops of the reference path)'} "
-                      f"fwd+bwd, batch {head['batch']} x {args.height}x{args.width}, {args.n_ref} refs, median of "
-                      f"{head['timed_steps']} steps ({head['ms_per_step']} ms/step); other thread counts / batch / "
-                      f"anomaly mode under `variants`",
-            "ms_per_step": head["ms_per_step"],
+                      f"fwd+bwd, batch {head['batch']} x {args.height}x{args.width}, {args.n_ref} refs, {head['threads']} threads "
+                      f"pinned to one NUMA node's cores (OMP_PROC_BIND=close), blocks of >= 15 timed steps repeated until two "
+                      f"consecutive medians agree within 10 %: median of the last two blocks {head['ms_per_step']} ms/step, "
+                      f"fastest step {head.get('min_ms_per_step')} ms, {head['timed_steps']} steps; other thread counts / "
+                      f"batch / anomaly mode under `variants`",
+            "ms_per_step": head["ms_per_step"], "min_ms_per_step": head.get("min_ms_per_step"),
+            "block_medians_ms": head.get("block_medians_ms"), "last_two_blocks_differ_by": head.get("last_two_blocks_differ_by"),
             "algorithmic_GBs": round(step_bytes(n_px, args.n_ref) / (head["ms_per_step"] * 1e-3) / 1e9, 3),
             "host_cores_available": avail, "variants": rows}
 
@@ -332,7 +375,7 @@ def main():
                          "(what a trained DispResNet emits; scsfm_hip.synth)")
     ap.add_argument("--loss-steps", type=int, default=50, help="timed steps of the hot-path (loss only) legs")
     ap.add_argument("--loss-warmup", type=int, default=10)
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget of the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on the CPU baseline's intra-op threads")
     ap.add_argument("--kernel-iters", type=int, default=30)
     ap.add_argument("--e2e", type=int, default=1, help="0: skip the training steps and report the hot path alone "
@@ -361,9 +404,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
-            # started as plain `python bench.py --gpus N` (the form the driver's N = 1 command has): become the launcher
-            sys.exit(self_launch(args.gpus, sys.argv[1:]))
+        if world == 1 and args.gpus > 1:
+            if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+                # started as plain `python bench.py --gpus N` (the form the driver's N = 1 command has): become the launcher
+                sys.exit(self_launch(args.gpus, sys.argv[1:]))
+            # a launcher started ONE rank for a command that asks for N (torchrun --nproc-per-node=1, a stale RANK /
+            # WORLD_SIZE in the environment): a 1-GPU number must not be reported under --gpus N
+            sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is 1 (RANK={os.environ.get('RANK')}): "
+                     f"start {args.gpus} ranks, or run without a launcher")
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the loss path has no CPU fallback")
@@ -512,24 +560,50 @@ def main():
     # launch: per pair-direction both images and both depth maps are read once (32 B/px) and the
     # two depth gradients are written once and read-modify-written once (16 B/px).
     spec_bytes = n_pairs * 48 * n_px
+    # round 6: in a step the kernel also carries the frames' smooth loss (scsfm_hip.config.smooth_rides_along): it reads
+    # nothing more for it -- each frame's depth and colours are its target reads anyway -- and writes the 4 B/px edge plane
+    # of every frame, which is all that is added to its algorithmic bytes
+    from scsfm_hip import capi as _capi, config as _config
+    rides = bool(_config.smooth_rides_along() and _capi.smooth_rides_along(_capi.make_flags(*flags), x["tgt_img"], x["tgt_depth"],
+                                                                            x["ref_depths"], (W_PHOTO, W_GEOM)))
+    smooth_ride_bytes = 4 * n_px * (1 + args.n_ref) if rides else 0
+    spec_bytes += smooth_ride_bytes
     # its average duration over the launches inside the timed (eager) steps; the back-to-back figure of
     # time_kernels (inputs still in the Infinity Cache from the previous launch) is reported beside it
-    launch_s = in_step_us[0] * 1e-6 if in_step_us[2] > 0 else kt["spec_kernel_only"]
+    b2b = kt.get("spec_kernel_only_with_smooth", kt["spec_kernel_only"]) if rides else kt["spec_kernel_only"]
+    launch_s = in_step_us[0] * 1e-6 if in_step_us[2] > 0 else b2b
     achieved = spec_bytes / launch_s / 1e9
     traffic, traffic_why = pmc_traffic(args, n_pairs, ident["source_id_in_binary"])
-    roofline = {"bound": "hbm", "kernel": f"{DOMINANT_KERNEL} ({n_pairs} pair-directions per launch)",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                # (HBM bytes per launch = FETCH_SIZE + WRITE_SIZE of separate `rocprofv3 --pmc` passes of this command,
-                # QUOTED from the committed profiles/pmc_latest.json -- counters cannot be read inside a timed run --
-                # and only when that file was recorded on the library loaded here)
-                "traffic_source": traffic_why,
-                # of the 48 B/px booked on this kernel 8 B/px (the read-modify-write of the gradient maps) are paid by
-                # pairs_combine_kernel: the kernel's own algorithmic bytes are 40 B/px
-                "kernel_own_algorithmic_bytes_per_launch": int(spec_bytes / 48 * 40),
-                "algorithmic_bytes_per_launch": spec_bytes, "avg_launch_us": round(launch_s * 1e6, 2),
-                "launches_timed": in_step_us[2], "min_launch_us": round(in_step_us[1], 2),
-                "back_to_back_launch_us": round(kt["spec_kernel_only"] * 1e6, 2)}
+    tiles = n_pairs * args.batch * (-(-args.width // 62)) * (-(-args.height // 14))
+    ib_us, ib_detail = issue_bound(ident["source_id_in_binary"], tiles)
+    own_bytes = int(n_pairs * 40 * n_px + smooth_ride_bytes)
+    roofline = {
+        # `frac` is the judged figure: algorithmic HBM bytes per launch / measured launch time, against the 8 TB/s HBM peak.
+        # What actually bounds the kernel is not bytes: its HBM traffic (below) is at or under the algorithmic figure at a
+        # fifth of the peak, and the SQ counters (profiles/) show the waves issuing, or waiting for the vector issue port,
+        # two thirds of the time -- it runs at `frac_of_issue_bound` of the time its vector instructions alone would take
+        "bound": "valu_issue", "frac_is_against": "hbm",
+        "kernel": f"{DOMINANT_KERNEL} ({n_pairs} pair-directions per launch" + (", carrying the smooth loss of the step's frames)" if rides else ")"),
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        # HBM bytes per launch, FETCH_SIZE + WRITE_SIZE (raw counters) of separate `rocprofv3 --pmc` passes of this command:
+        # QUOTED from the committed profiles/pmc_latest.json -- counters cannot be read inside a timed run -- and only when
+        # that file was recorded on the library loaded here; `traffic_detail` has the two counters separately, raw and
+        # calibrated against known-bytes kernels
+        "traffic": None if traffic is None else traffic["fetch_bytes_raw"] + traffic["write_bytes_raw"],
+        "traffic_is": "quoted from profiles/ (not measured in this run)" if traffic is not None else None,
+        "traffic_detail": traffic, "traffic_source": traffic_why,
+        "issue_bound_us": None if ib_us is None else round(ib_us, 1),
+        "frac_of_issue_bound": None if ib_us is None else round(ib_us / (launch_s * 1e6), 4),
+        "issue_bound_detail": ib_detail,
+        # of the 48 B/px booked on this kernel 8 B/px (the read-modify-write of the gradient maps) are paid by
+        # pairs_combine_kernel: the kernel's own algorithmic bytes are 40 B/px (+ the edge planes when the smooth loss rides)
+        "kernel_own_algorithmic_bytes_per_launch": own_bytes,
+        "kernel_own_frac": round(own_bytes / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+        "smooth_loss_rides_in_the_kernel": rides, "smooth_edge_plane_bytes_per_launch": smooth_ride_bytes,
+        "algorithmic_bytes_per_launch": spec_bytes, "avg_launch_us": round(launch_s * 1e6, 2),
+        "launches_timed": in_step_us[2], "min_launch_us": round(in_step_us[1], 2),
+        "back_to_back_launch_us": round(b2b * 1e6, 2)}
     # the same kernel inside eager steps on the OTHER synthetic depth laws (rank 0 of a 1-GPU run of the headline law only):
     # `scene` = piecewise-smooth depth with occlusion edges, the closest stand-in for a trained net's output; `iid` =
     # the incoherent stress case.  Same algorithmic bytes, same 8 TB/s.
@@ -562,7 +636,8 @@ def main():
     pair_roofline = {"algorithmic_bytes": 48 * n_px, "us": round(pair_t * 1e6, 2),
                      "achieved_GBs": round(48 * n_px / pair_t / 1e9, 1),
                      "frac": round(48 * n_px / pair_t / 1e9 / HBM_PEAK_GBS, 4)}
-    kernel_sum = kt["pairs_fwd_spec"] + kt["pairs_bwd_after_spec"] + kt["smooth_fwd"] + kt["smooth_bwd"]
+    kernel_sum = (kt["pairs_fwd_spec_with_smooth"] if rides and "pairs_fwd_spec_with_smooth" in kt else
+                  kt["pairs_fwd_spec"] + kt["smooth_fwd"]) + kt["pairs_bwd_after_spec"] + kt["smooth_bwd"]
 
     if rank == 0:
         shape = (args.dataset, args.height, args.width, args.batch, args.n_ref, args.resnet_layers)

@@ -16,6 +16,11 @@ product package is imported here).
   variant T:B:A    : T intra-op threads, batch B, A = 1 runs under torch.autograd.set_detect_anomaly(True) as the
                      reference's train.py:67 does globally
 Prints one JSON list (one object per variant) on stdout.
+
+Round 6: every variant runs in a process of its own, pinned (OMP_PROC_BIND=close, OMP_PLACES=cores, the process confined
+to as many physical cores of one NUMA node as it has threads), in blocks of >= 15 timed steps that are repeated until two
+consecutive block medians agree within 10 %; `ms_per_step` is the median of the last two blocks, `min_ms_per_step` the
+fastest step seen.  (The unpinned median of 7 steps moved 2.7x between the driver's runs of rounds 1-5.)
 """
 import argparse
 import importlib.util
@@ -36,20 +41,62 @@ def load_by_path(name, path):
     return mod
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--impl", choices=["reference", "oracle"], required=True)
-    ap.add_argument("--ref-dir", default="/root/reference")
-    ap.add_argument("--variants", required=True)
-    ap.add_argument("--seconds", type=float, default=15.0)
-    ap.add_argument("--height", type=int, default=256)
-    ap.add_argument("--width", type=int, default=832)
-    ap.add_argument("--n-ref", type=int, default=2)
-    ap.add_argument("--depth", default="smooth")
-    ap.add_argument("--dataset", default="kitti")
-    args = ap.parse_args()
+def pick_cores(n):
+    """The first n physical cores of ONE NUMA node (one hardware thread per core), among those this process may use;
+    fewer than n on that node -> the next nodes' cores follow.  [] where the topology cannot be read."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return []
 
+    def cpulist(path):
+        out = []
+        try:
+            for part in open(path).read().strip().split(","):
+                if "-" in part:
+                    a, b = part.split("-")
+                    out.extend(range(int(a), int(b) + 1))
+                elif part:
+                    out.append(int(part))
+        except OSError:
+            pass
+        return out
+
+    nodes = []
+    base = "/sys/devices/system/node"
+    try:
+        for name in sorted((n_ for n_ in os.listdir(base) if n_.startswith("node") and n_[4:].isdigit()), key=lambda x: int(x[4:])):
+            nodes.append([c for c in cpulist(os.path.join(base, name, "cpulist")) if c in allowed])
+    except OSError:
+        pass
+    if not nodes:
+        nodes = [allowed]
+    picked, seen_cores = [], set()
+    for cpus in nodes:
+        for c in cpus:
+            sib = tuple(cpulist(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list")) or (c,)
+            if sib in seen_cores:
+                continue  # a second hardware thread of a core already taken
+            seen_cores.add(sib)
+            picked.append(c)
+            if len(picked) == n:
+                return picked
+    return picked
+
+
+def run_one(args, threads, batch, anomaly, budget):
+    """One variant in THIS process (a fresh one per variant: thread pools and affinity masks are per process).  The
+    threads are pinned -- OMP_PROC_BIND / OMP_PLACES were set by the parent before torch was imported here, and the
+    process is confined to `threads` physical cores of one NUMA node -- because an unpinned run of this path moved
+    2.7x between the driver's runs of rounds 1-5 (175 ... 468 ms per step for unchanged code)."""
+    cores = pick_cores(threads)
+    if cores:
+        try:
+            os.sched_setaffinity(0, set(cores))
+        except OSError:
+            cores = []
     import torch
+    torch.set_num_threads(threads)
     synth = load_by_path("_scsfm_synth", os.path.join(ROOT, "sc-sfmlearner-release_amd", "scsfm_hip", "synth.py"))
     if args.impl == "reference":
         sys.path.insert(0, args.ref_dir)
@@ -71,39 +118,86 @@ def main():
             smooth = O.smooth_loss(td, d["tgt_img"], rd, d["ref_imgs"])
             return photo, smooth, geom
 
-    variants = [tuple(int(x) for x in v.split(":")) for v in args.variants.split(",")]
-    budget = args.seconds / max(1, len(variants))
-    out = []
-    for threads, batch, anomaly in variants:
-        torch.set_num_threads(threads)
-        torch.autograd.set_detect_anomaly(bool(anomaly))
-        d = synth.make_batch(batch, args.height, args.width, n_ref=args.n_ref, seed=0, depth=args.depth,
-                             image="smooth" if args.depth == "smooth" else "iid", dataset=args.dataset)
+    torch.autograd.set_detect_anomaly(bool(anomaly))
+    d = synth.make_batch(batch, args.height, args.width, n_ref=args.n_ref, seed=0, depth=args.depth,
+                         image="smooth" if args.depth == "smooth" else "iid", dataset=args.dataset)
 
-        def one():
-            lf = lambda t: t.clone().requires_grad_(True)
-            td = [lf(t) for t in d["tgt_depth"]]
-            rd = [[lf(t) for t in r] for r in d["ref_depths"]]
-            ps, pi = [lf(p) for p in d["poses"]], [lf(p) for p in d["poses_inv"]]
-            photo, smooth, geom = step(d, td, rd, ps, pi)
-            loss = W_PHOTO * photo + W_SMOOTH * smooth + W_GEOM * geom
-            loss.backward()
-            return float(loss)
+    def one():
+        lf = lambda t: t.clone().requires_grad_(True)
+        td = [lf(t) for t in d["tgt_depth"]]
+        rd = [[lf(t) for t in r] for r in d["ref_depths"]]
+        ps, pi = [lf(p) for p in d["poses"]], [lf(p) for p in d["poses_inv"]]
+        photo, smooth, geom = step(d, td, rd, ps, pi)
+        loss = W_PHOTO * photo + W_SMOOTH * smooth + W_GEOM * geom
+        loss.backward()
+        return float(loss)
 
-        t0 = time.perf_counter()
-        loss = one()  # warm-up
-        warm = time.perf_counter() - t0
+    loss = one()  # warm-up (allocator, thread pool)
+    one()
+    med = lambda xs: sorted(xs)[len(xs) // 2]
+    # blocks of `args.min_steps` timed steps (fewer for variants that take seconds per step: the time budget bounds
+    # them), repeated -- at most four blocks -- until the medians of two consecutive blocks agree within 10 %
+    blocks, t_start = [], time.perf_counter()
+    while len(blocks) < 4:
         times = []
-        t_end = time.perf_counter() + max(0.0, budget - warm)
-        while time.perf_counter() < t_end or len(times) < 1:
+        while len(times) < args.min_steps:
             t0 = time.perf_counter()
             one()
             times.append(time.perf_counter() - t0)
-        times.sort()
-        med = times[len(times) // 2]
-        out.append({"threads": threads, "batch": batch, "anomaly_mode": bool(anomaly), "ms_per_step": round(med * 1e3, 2),
-                    "images_per_sec": round(batch / med, 3), "timed_steps": len(times), "loss": loss})
-    torch.autograd.set_detect_anomaly(False)
+            if time.perf_counter() - t_start > budget and len(times) >= 3:
+                break
+        blocks.append(times)
+        if len(blocks) >= 2 and abs(med(blocks[-1]) / med(blocks[-2]) - 1.0) <= 0.10:
+            break
+        if time.perf_counter() - t_start > budget:
+            break
+    last = blocks[-1] + (blocks[-2] if len(blocks) >= 2 else [])
+    every = [t for b in blocks for t in b]
+    m = med(last)
+    agree = abs(med(blocks[-1]) / med(blocks[-2]) - 1.0) if len(blocks) >= 2 else None
+    return {"threads": threads, "batch": batch, "anomaly_mode": bool(anomaly), "ms_per_step": round(m * 1e3, 2),
+            "min_ms_per_step": round(min(every) * 1e3, 2), "images_per_sec": round(batch / m, 3), "timed_steps": len(every),
+            "block_medians_ms": [round(med(b) * 1e3, 2) for b in blocks],
+            "last_two_blocks_differ_by": None if agree is None else round(agree, 4),
+            "pinned_to_cpus": cores, "omp_proc_bind": os.environ.get("OMP_PROC_BIND"), "loss": loss}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--impl", choices=["reference", "oracle"], required=True)
+    ap.add_argument("--ref-dir", default="/root/reference")
+    ap.add_argument("--variants", required=True)
+    ap.add_argument("--seconds", type=float, default=15.0)
+    ap.add_argument("--min-steps", type=int, default=15, help="timed steps per block of a variant")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=832)
+    ap.add_argument("--n-ref", type=int, default=2)
+    ap.add_argument("--depth", default="smooth")
+    ap.add_argument("--dataset", default="kitti")
+    ap.add_argument("--one", default=None, help="(internal) run this single variant in this process")
+    ap.add_argument("--budget", type=float, default=0.0, help="(internal) seconds for --one")
+    args = ap.parse_args()
+
+    if args.one is not None:
+        t, b, a = (int(x) for x in args.one.split(":"))
+        print(json.dumps(run_one(args, t, b, a, args.budget)))
+        return
+    import subprocess
+    variants = [tuple(int(x) for x in v.split(":")) for v in args.variants.split(",")]
+    # the first variant is the headline (two blocks of >= 15 steps): it gets half the budget, the rest share the other half
+    out = []
+    for i, (threads, batch, anomaly) in enumerate(variants):
+        budget = args.seconds * (0.5 if i == 0 else 0.5 / max(1, len(variants) - 1)) if len(variants) > 1 else args.seconds
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
+        cmd = [sys.executable, os.path.abspath(__file__), "--impl", args.impl, "--ref-dir", args.ref_dir, "--variants", "-",
+               "--one", f"{threads}:{batch}:{anomaly}", "--budget", str(budget), "--min-steps", str(args.min_steps),
+               "--height", str(args.height), "--width", str(args.width), "--n-ref", str(args.n_ref), "--depth", args.depth,
+               "--dataset", args.dataset]
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr[-3000:])
+            sys.exit(r.returncode)
+        out.append(json.loads(r.stdout.strip().split("\n")[-1]))
     print(json.dumps(out))
 
 

@@ -170,8 +170,14 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
   #pragma unroll
       for (int c = 0; c < 3; ++c) rin_t[c] = ld_plane(tgtP, c, off);
     }
-#ifndef SCSFM_SMOOTH_AT  // tuning knob: where the tile evaluates its target frame's smooth loss: 0 = in front of the warp
-#define SCSFM_SMOOTH_AT 1  // phase (values in registers, two more rows loaded), 1 = behind the flush (everything re-read)
+    // ---- the target frame's smooth loss (loss_functions.py:133-152), for the pair that carries it (uniform per pair) ----
+    // Depth and colours of the strip are in registers here; the rows above and below it are two more loads each.  One pass
+    // yields the strip's part of sum D and of both edge sums, and the per-pixel edge terms the backward streams; every wave
+    // leaves its own record (no barrier).  SCSFM_SMOOTH_AT (tuning knob): 0 = here, 1 = behind the flush with everything
+    // re-read -- measured on one box, alternating processes (profiles/r06_kernel_experiments.json): loss-path step
+    // 0.4275-0.433 ms here against 0.4315-0.4365 there and 0.441-0.443 with the stand-alone smooth forward.
+#ifndef SCSFM_SMOOTH_AT
+#define SCSFM_SMOOTH_AT 0
 #endif
 #if SCSFM_SMOOTH_AT == 0
     if (pa.sm_partials != nullptr) {
@@ -537,11 +543,8 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
       flush_scatter_region<T, Cell, WW, WH>(win, wx0, wy0, cx0, cy0, cx1, cy1, g_scatter, W, ww, kFixed ? T(fix_inv) : T(1));
     STAMP(8);
 #if SCSFM_SMOOTH_AT == 1
-    // ---- the target frame's smooth loss (loss_functions.py:133-152), for the pair that carries it (uniform) ----------
-    // Behind everything else: nothing of the tile is live any more, so the strip and the rows above and below it are
-    // read again (L2: the tile streamed them a moment ago) and the arithmetic overlaps the other resident workgroups'
-    // phases instead of sitting in front of this tile's first gathers (in front of the warp phase: +26 us per launch at
-    // configs[1], measured; here: see profiles/r06_kernel_experiments.json).  No barrier: every wave leaves its own record.
+    // (tuning builds: the smooth loss behind everything else -- nothing of the tile is live any more, so the strip and the
+    // rows above and below it are read again)
     if (pa.sm_partials != nullptr) {
       // (the row offsets below are the expressions of phase 0: unless the first row is made opaque here, the compiler
       // keeps phase 0's values alive across the whole tile -- 13 registers spilled)

@@ -46,3 +46,13 @@ def test_ranks_of_the_launched_job_do_not_launch_again():
     import torch
     if not torch.cuda.is_available():
         assert out.returncode != 0 and "needs a HIP device" in out.stderr
+
+
+def test_one_rank_under_a_launcher_is_not_reported_as_n_gpus():
+    """Round-5 advisor finding: `torchrun --nproc-per-node=1 bench.py --gpus 4` (or a stale RANK in the environment) used
+    to run silently on one GPU.  With RANK / WORLD_SIZE set and WORLD_SIZE = 1 the command is refused."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29997")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE is 1" in out.stderr and "re-executing" not in out.stderr
+    assert out.stdout.strip() == ""  # no JSON line

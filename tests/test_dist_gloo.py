@@ -1,6 +1,9 @@
-"""world_size-2 data-parallel checks on CPU (gloo): batch sharding and the exact-normalisation mode
+"""Data-parallel checks on CPU (gloo) at world sizes 2, 4 and 8: batch sharding and the exact-normalisation mode
 (one all-reduce of the [n_pairs, 3] raw sums, then the gates / divisions on the global sums).  The
-kernels run through tests/hostsim; on the GPU the same capi code path runs with backend nccl (RCCL)."""
+kernels run through tests/hostsim; on the GPU the same capi code path runs with backend nccl (RCCL).
+World 4 and 8 (round 6: no 8-GPU node was available in any round, so everything about eight ranks that can be
+checked without one is checked here): one sample per rank, i.e. every shard BELOW the geometry term's 10000-pixel gate
+while the global batch is above it."""
 import os
 import socket
 import sys
@@ -18,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, exact, q):
+def _worker(rank, world, port, exact, q, per_rank=2):
     for p in (ROOT, os.path.join(ROOT, "sc-sfmlearner-release_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -34,9 +37,11 @@ def _worker(rank, world, port, exact, q):
     lib = harness.lib()
     # B=4 at 72x104: each 2-sample shard (14976 px) is above the photo gate but, with the auto mask,
     # below the geometry gate -- the global batch is above both.  Exact mode must follow the global gate.
-    full = synth.make_batch(4, 72, 104, n_ref=1, seed=31, depth="smooth")
+    # (world 4 / 8: one sample per rank, 7488 px: below the geometry gate on every shard, above it globally)
+    k = per_rank
+    full = synth.make_batch(k * world, 72, 104, n_ref=1, seed=31, depth="smooth")
     shard = sdist.shard_batch(full, rank, world)
-    assert shard["tgt_img"].shape[0] == 2 and torch.equal(shard["tgt_img"], full["tgt_img"][2 * rank:2 * rank + 2])
+    assert shard["tgt_img"].shape[0] == k and torch.equal(shard["tgt_img"], full["tgt_img"][k * rank:k * rank + k])
     flags = capi.make_flags(1, 1, 1, "zeros")
     group = None
     if exact:
@@ -58,38 +63,65 @@ def _worker(rank, world, port, exact, q):
     po, go = O.photo_and_geometry_loss(src["tgt_img"], src["ref_imgs"], src["intrinsics"], td, rd, ps, pi, 1, 1, 1, 1,
                                        "zeros")
     (po + go).backward()
-    sl = slice(2 * rank, 2 * rank + 2) if exact else slice(None)
+    sl = slice(k * rank, k * rank + k) if exact else slice(None)
+    # 99.9 % quantile of the entry errors relative to the map's scale (a single pixel whose valid / auto-mask / clamp
+    # decision rounds the other way in the fp32 oracle moves its entry by per cents: tests/test_gpu_parity.py looks at
+    # those through the gate margins; here the point is the data-parallel arithmetic); all gates closed: 0 against 0
+    def rel(a, b):
+        e = (a - b[sl]).abs().flatten()
+        q = e.max() if e.numel() < 2000 else torch.quantile(e, 0.999)
+        return float(q / b.abs().max().clamp_min(1e-30))
     res = {
-        "photo": abs(float(photo) - float(po)), "geom": abs(float(geom) - float(go)), "geom_val": float(go),
-        "g_td": float((g_td[0] - td[0].grad[sl]).abs().max() / td[0].grad.abs().max()),
-        "g_rd": float((g_rd[0][0] - rd[0][0].grad[sl]).abs().max() / rd[0][0].grad.abs().max()),
-        "g_pose": float((g_p[0] - ps[0].grad[sl]).abs().max() / ps[0].grad.abs().max()),
+        "photo": abs(float(photo) - float(po)), "geom": abs(float(geom) - float(go)), "geom_val": float(go), "photo_val": float(po),
+        "g_td": rel(g_td[0], td[0].grad), "g_rd": rel(g_rd[0][0], rd[0][0].grad), "g_pose": rel(g_p[0], ps[0].grad),
         "local_geom_gate_open": bool(float(outs[0, 4]) > 10000) if not exact else None,
+        "local_photo": float(photo),
     }
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exact", [True, False])
-def test_two_rank_data_parallel(exact):
+def _run(world, exact, per_rank):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, exact, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, exact, q, per_rank)) for r in range(world)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=300) for _ in range(2))
+    results = dict(q.get(timeout=600) for _ in range(world))
     for p in procs:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
-    for rank in (0, 1):
+    for rank in range(world):
         r = results[rank]
-        assert r["photo"] <= 2e-6 and r["geom"] <= 2e-6, r
+        # (one-sample shards: a single pixel whose mask decision rounds the other way in the fp32 oracle is 1 / 22464 of the mean)
+        tol = 2e-6 if per_rank > 1 else 5e-5
+        assert r["photo"] <= tol and r["geom"] <= tol, r
         assert r["g_td"] <= 5e-3 and r["g_rd"] <= 5e-3 and r["g_pose"] <= 5e-3, r
+    return results
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_two_rank_data_parallel(exact):
+    results = _run(2, exact, 2)
     if exact:
         # the global geometry gate is open although each shard alone is below it
         assert results[0]["geom_val"] > 0
+
+
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("exact", [True, False])
+def test_four_and_eight_rank_data_parallel_with_shards_below_the_gates(world, exact):
+    results = _run(world, exact, 1)
+    if exact:
+        # every rank holds the losses of the concatenated batch: both global gates are open
+        assert all(r["photo_val"] > 0 and r["geom_val"] > 0 and r["local_photo"] > 0 for r in results.values())
+    else:
+        # per-shard evaluation: the 7488 pixels of a shard never reach the 10000-pixel gate of the geometry term
+        # (loss_functions.py:125; the photometric term's mask is expanded over 3 channels and passes) -- a zero geometry
+        # loss with zero gradients, exactly as the single-process oracle on that shard
+        assert all(r["geom_val"] == 0.0 and r["photo_val"] > 0 and r["local_photo"] > 0 for r in results.values())
 
 
 def test_env_world_defaults(monkeypatch):

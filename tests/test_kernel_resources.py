@@ -72,11 +72,13 @@ def test_the_dominant_kernel_fits_four_workgroups_per_cu_and_spills_nothing(list
     assert len(flush_atomics) >= 2, "the flush's atomics no longer use the scalar-base addressing mode"
     # the kernel sits at the limit of the scalar file: anything that adds live scalars (a run-time XCD chunk size did)
     # pushes the image descriptors into vector registers -- caught by _waterfalls above; the count itself is recorded
-    assert 0 < meta["NumSGPRsForWavesPerEU"] <= 102, meta
+    # (the figure includes VCC, FLAT_SCRATCH and XNACK_MASK: 102 general-purpose scalars + 6; round 6: 100 + 6)
+    assert 0 < meta["NumSGPRsForWavesPerEU"] <= 108, meta
     valu = sum(1 for l in body if l.startswith("\tv_"))
     # (static count: 2599 on the path of a tile with a coherent footprint + the uniformly skipped code of the wide
-    # scatter window)
-    assert valu <= 2850, f"{valu} vector instructions per thread (round 3: 2773)"
+    # scatter window; round 6: + ~60 for the bound of the scatter cells' unit, + ~260 behind the flush that only the
+    # pair-directions carrying their target frame's smooth loss execute -- uniformly skipped by the others)
+    assert valu <= 3200, f"{valu} vector instructions per thread (round 3: 2773, round 5: 2802)"
 
 
 def test_the_plain_forward_spills_nothing(listing):
