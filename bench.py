@@ -432,6 +432,8 @@ def main():
         backend = "gloo" if shared_gpu else ("nccl" if world > 1 else args.force_dist)
         # (the same call train.py makes: nccl bound to this rank's device, gloo for ranks sharing a GPU)
         hip_dist.init_process_group(backend, rank, world, device, force=True)
+        if world > 1:  # as train.py does: every rank on its own block of the host's cores (nothing at world size 1)
+            hip_dist.pin_rank_to_its_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     import loss_functions as LF
     from scsfm_hip import _lib

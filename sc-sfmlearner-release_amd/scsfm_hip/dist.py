@@ -104,3 +104,43 @@ def shard_batch(batch, rank, world):
         return x
 
     return {k: rec(v) for k, v in batch.items()}
+
+
+def rank_cpu_block(local_rank, local_world, allowed):
+    """This rank's share of the host cores: the ``local_rank``-th of ``local_world`` contiguous, equally sized blocks of
+    the sorted CPU ids the job may use (contiguous ids share a NUMA node / L3 on the hosts of the pool; the remainder of
+    an uneven division is left to the operating system).  Fewer cores than ranks -> every rank keeps them all."""
+    allowed = sorted(allowed)
+    if local_world <= 1 or len(allowed) < local_world:
+        return allowed
+    k = len(allowed) // local_world
+    return allowed[local_rank * k:(local_rank + 1) * k]
+
+
+def pin_rank_to_its_cores(local_rank=None, local_world=None, max_threads=8):
+    """One process per GPU on one node: confine this rank -- and the data-loader workers it forks later, which inherit
+    the mask -- to its block of the host's cores, and size torch's intra-op pool to it (at most ``max_threads``: the
+    host side of a training step is launch-bound, not compute-bound).  Eight unpinned ranks with the default pool (one
+    thread per core of a 256-core host each) oversubscribe the host 8x and migrate across NUMA nodes.  Returns the block
+    (a list of CPU ids), or None where the platform has no affinity call or nothing was to be done."""
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", 1)))
+    if local_world <= 1 or not hasattr(os, "sched_getaffinity"):
+        return None
+    block = rank_cpu_block(local_rank, local_world, os.sched_getaffinity(0))
+    try:
+        os.sched_setaffinity(0, set(block))
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, min(max_threads, len(block))))
+    return block
+
+
+def loader_workers_for_rank(requested, block):
+    """Data-loader workers of one rank: what was asked for (the reference's -j, default 4), but no more than the rank's
+    cores minus one for the training process itself."""
+    if block is None:
+        return requested
+    return max(0, min(requested, len(block) - 1))

@@ -89,6 +89,9 @@ parser.add_argument('--channels-last', type=int, default=0,
                     help='1: both nets (weights and activations) in NHWC memory format -- MIOpen\'s fp32 igemm solvers then need '
                          'no NCHW<->NHWC transposes around them; the loss path keeps reading the NCHW batch.  Off by default: '
                          'other solvers, other rounding (losses equal to ~1e-6, not bit for bit)')
+parser.add_argument('--rank-affinity', default='auto', choices=['auto', 'off'],
+                    help='data parallel: auto = every rank (and the loader workers it forks) is confined to its share of the '
+                         'host cores and -j is capped to that share; off = leave placement to the operating system')
 parser.add_argument('--exact-mask-normalisation', action='store_true',
                     help='data parallel: all-reduce the mask sums so the loss equals the single-process loss on the global batch. '
                          '(BatchNorm running statistics stay per rank either way -- as per replica under the reference\'s '
@@ -162,6 +165,15 @@ def main():
                            "--with-pretrain 0 (optionally with --pretrained-disp / --pretrained-pose)")
     rank, local_rank, world = hip_dist.init_process_group_from_env()
     is_main = rank == 0
+    if world > 1 and args.rank_affinity == 'auto':
+        # eight ranks on one host: each on its own block of cores, loader workers included (they inherit the mask)
+        block = hip_dist.pin_rank_to_its_cores(local_rank)
+        workers = hip_dist.loader_workers_for_rank(args.workers, block)
+        if block is not None:
+            print("=> rank {}: cores {}-{} ({}), {} intra-op threads, {} loader workers{}".format(
+                rank, block[0], block[-1], len(block), torch.get_num_threads(), workers,
+                " (capped from -j {})".format(args.workers) if workers != args.workers else ""))
+        args.workers = workers
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)

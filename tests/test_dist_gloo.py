@@ -132,3 +132,17 @@ def test_env_world_defaults(monkeypatch):
     assert sdist.exact_group() is None
     with pytest.raises(ValueError):
         sdist.shard_batch({"x": torch.zeros(3, 2)}, 0, 2)
+
+
+def test_rank_cpu_blocks_partition_the_host():
+    """Eight ranks on one host (train.py --rank-affinity auto): disjoint, equally sized, contiguous blocks; -j capped."""
+    from scsfm_hip import dist as sdist
+    allowed = list(range(256))
+    blocks = [sdist.rank_cpu_block(r, 8, allowed) for r in range(8)]
+    assert all(len(b) == 32 and b == list(range(b[0], b[0] + 32)) for b in blocks)
+    assert sorted(c for b in blocks for c in b) == allowed
+    assert sdist.rank_cpu_block(3, 8, range(4)) == [0, 1, 2, 3]            # fewer cores than ranks: shared
+    assert sdist.rank_cpu_block(1, 3, [0, 2, 4, 6, 8, 10, 12]) == [4, 6]   # a sparse mask, uneven division
+    assert sdist.loader_workers_for_rank(4, blocks[0]) == 4 and sdist.loader_workers_for_rank(16, [0, 1, 2]) == 2
+    assert sdist.loader_workers_for_rank(4, None) == 4
+    assert sdist.pin_rank_to_its_cores(0, 1) is None                        # a single rank is left alone

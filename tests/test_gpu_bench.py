@@ -22,20 +22,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
-MIOPEN_CRASH = ("GemmBwdRest", "MIOpen", "miopen")  # what the one crash this retry exists for leaves on stderr
+MIOPEN_TOKENS = ("GemmBwdRest", "MIOpen", "miopen")  # what the one crash this retry exists for leaves on stderr
+RETRIED = []  # (command, stderr tail) of every retry of this session: the last test of the module reports them
 
 
 def _run(cmd, env, timeout=900):
     """bench.py in a subprocess.  One retry ONLY for the known crash: on one box of the pool a MIOpen backward solver
     (GemmBwdRest, requested with a null workspace at this reduced shape) took the process down with 'Memory access
-    fault ... address (nil)' once in six sessions of round 4 -- inside the nets' backward, not in this library.  A
-    process killed by a signal WITHOUT that signature on stderr (a fault at a non-null address, an abort, a kill) is not
-    retried: the caller's assertion on the return code fails with its stderr."""
+    fault ... address (nil)' once in six sessions of round 4 -- inside the nets' backward, not in this library.  The retry
+    needs BOTH signatures on stderr (round-5 review: the nil-address line alone names no library, a null-address fault
+    of this library's own kernels must not be retried away): a MIOpen token AND the nil-address fault.  Any other death
+    by signal is not retried: the caller's assertion on the return code fails with its stderr.  Every retry is
+    recorded and surfaces as an xfail in the summary (test_no_bench_subprocess_had_to_be_retried)."""
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    # (the fault line itself -- "Memory access fault by GPU node-N ... on address (nil)" -- names no library; a fault of this
-    # library's kernels at a NULL address is not excluded by it, hence the warning, which pytest prints in its summary)
-    if out.returncode < 0 and ("address (nil)" in out.stderr or any(k in out.stderr for k in MIOPEN_CRASH)):
+    if out.returncode < 0 and "address (nil)" in out.stderr and any(k in out.stderr for k in MIOPEN_TOKENS):
         import warnings
+        RETRIED.append((" ".join(cmd[-12:]), out.stderr[-400:]))
         warnings.warn(f"bench.py died with signal {-out.returncode} inside MIOpen (known, null-workspace solver); "
                       f"retrying once.  stderr tail: {out.stderr[-400:]}")
         out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
@@ -58,14 +60,21 @@ def test_single_gpu_line_has_the_contract_fields():
     assert r["train"]["final_loss"] == r["train"]["final_loss"]
     assert 0 < r["warp_loss_ms_per_step"] < r["ms_per_step"]
     rf = r["roofline"]
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["launches_timed"] == 3
+    # `frac` is against the HBM peak (the judged figure); what bounds the kernel is named truthfully beside it
+    assert rf["bound"] == "valu_issue" and rf["frac_is_against"] == "hbm" and rf["peak"] == 8000.0 and rf["launches_timed"] == 3
+    assert rf["smooth_loss_rides_in_the_kernel"] is True and rf["smooth_edge_plane_bytes_per_launch"] == 4 * 2 * 128 * 416 * 3
+    assert abs(rf["kernel_own_frac"] - rf["kernel_own_algorithmic_bytes_per_launch"] / rf["avg_launch_us"] / 1e3 / 8000.0) < 1e-3
+    if rf["issue_bound_us"] is not None:  # (quoted for the library the static cost was computed on)
+        assert abs(rf["frac_of_issue_bound"] - rf["issue_bound_us"] / rf["avg_launch_us"]) < 1e-3
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / rf["avg_launch_us"] / 1e3) < 0.01 * rf["achieved"]
     cb = r["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["variants"]) >= 3
     assert {v["threads"] for v in cb["variants"]} >= {1} and any(v["anomaly_mode"] for v in cb["variants"])
+    # pinned, in blocks, with the fastest step beside the median (round 6)
+    assert cb["min_ms_per_step"] <= cb["ms_per_step"] and cb["block_medians_ms"] and all(v["omp_proc_bind"] == "close" for v in cb["variants"])
     lib = r["library"]
-    assert lib["path"].endswith("scsfm_hip/libscsfm_hip.so") and lib["abi_version"] == 8 and not lib["env_override"]
+    assert lib["path"].endswith("scsfm_hip/libscsfm_hip.so") and lib["abi_version"] == 9 and not lib["env_override"]
     # the binary names the sources it was built from, and they are the tree's
     assert lib["source_id_in_binary"] == lib["source_sha256_16"] and len(lib["source_sha256_16"]) == 16
     assert r["collective_backend"] is None and r["rccl_ranks"] == 1
@@ -113,3 +122,28 @@ def test_gpus_2_without_a_launcher_launches_itself():
     assert r["n_gpus"] == 2 and r["collective_ranks"] == 2 and r["config"]["global_batch"] == 4
     assert r["steps"] == 2 and r["value"] > 0 and "ddp2" in r["config"]["parallelism"]
     assert "re-executing as" in out.stderr
+
+
+def test_eight_ranks_on_the_one_gpu_run_the_drivers_scaling_command():
+    """The driver's 8-GPU command -- `python bench.py --gpus 8 ...`, no launcher -- as far as a 1-GPU box can take it: eight
+    ranks that share the GPU (SCSFM_BENCH_SHARED_GPU=1: gloo between them), self-launch, rendezvous on 127.0.0.1, the
+    nets in DistributedDataParallel, rank 0's one JSON line with n_gpus = collective_ranks = 8 and a global batch of
+    8 x per-rank.  No 8-GPU node was available to any round: this is what stands in for it."""
+    env = dict(os.environ, SCSFM_BENCH_SHARED_GPU="1", SCSFM_CUDNN_BENCHMARK="0", MIOPEN_FIND_MODE="FAST", OMP_NUM_THREADS="4")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    small = ["--steps", "2", "--warmup", "1", "--loss-steps", "2", "--loss-warmup", "1", "--kernel-iters", "1", "--batch", "1",
+             "--height", "128", "--width", "416", "--other-laws", "0"]
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", *small, "--cpu-seconds", "0"], env, timeout=1500)
+    r = _last_json(out)
+    assert r["n_gpus"] == 8 and r["collective_ranks"] == 8 and r["collective_backend"] == "gloo" and "rccl_ranks" not in r
+    assert r["config"]["global_batch"] == 8 and "ddp8" in r["config"]["parallelism"] and r["scaling"] == "weak"
+    assert r["steps"] == 2 and r["value"] > 0 and r["train"]["final_loss"] == r["train"]["final_loss"]
+    assert "cpu_baseline" not in r  # rank 0 at N = 1 only
+    assert "re-executing as" in out.stderr
+
+
+def test_no_bench_subprocess_had_to_be_retried():
+    """Last in the module: a retry of the known MIOpen crash does not fail the suite, but it must be visible."""
+    if RETRIED:
+        pytest.xfail(f"{len(RETRIED)} bench subprocess(es) died inside MIOpen and were retried once: {RETRIED}")
