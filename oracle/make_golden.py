@@ -203,6 +203,10 @@ def gen_cfg1():
         blob[f"{name}/checks"] = np.array([float(g.sum()), float(g.abs().sum()), float(g.norm()),
                                            float((g * probe(g.numel()).double()).sum()), float(g.abs().max())])
         blob[f"{name}/sample"] = npy(t.grad.reshape(-1)[::997])
+        # round 6: a denser sample (every 191st entry: 13.4 k per map, 191 is prime to the row length) of the reference's
+        # OWN fp32 gradients -- the comparand of tests/test_gpu_parity.py's entry-wise judgement at this size, next to
+        # the oracle's fp32 run that judgement used so far
+        blob[f"{name}/sample191"] = npy(t.grad.reshape(-1)[::191])
     for i in range(2):
         blob[f"g_pose{i}"] = npy(ps[i].grad)
         blob[f"g_pose_inv{i}"] = npy(pi[i].grad)
@@ -242,6 +246,13 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(1)
+    if sys.argv[1:] == ["cfg1"]:  # only the configs[1]-size fixture (the other files stay byte for byte)
+        # (this fixture was recorded with torch's default intra-op pool: synth.make_batch's image normalisation sums in another
+        # order on ONE thread, 5e-10 relative in the inputs -- the tests check the inputs against `input_check`)
+        torch.set_num_threads(max(2, os.cpu_count() or 2))
+        gen_cfg1()
+        print("cfg1_reference.npz", os.path.getsize(os.path.join(OUT, "cfg1_reference.npz")))
+        return
     for name, (B, H, W, seed, dep, im) in SETS.items():
         d = synth.make_batch(B, H, W, n_ref=2, seed=seed, depth=dep, image=im, num_scales=2)
         save_inputs(name, d)

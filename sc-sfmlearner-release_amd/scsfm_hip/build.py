@@ -53,7 +53,13 @@ def source_id(extra=()):
     counters to a library by this id).  It is compiled into the binary (scsfm_source_id) so that a loaded .so can be
     tied to the sources next to it."""
     h = hashlib.sha256()
-    for path in deps():
+    files = deps()
+    if any("SCSFM_WITH_MARCH" in e or "variants" in e for e in extra):
+        # tuning builds compile the experimental kernels of variants/src/ in: an edit there must change the id too (round-5
+        # advisor finding: PMC counters could be attributed to a stale variant binary)
+        vsrc = os.path.join(os.path.dirname(os.path.dirname(HERE)), "variants", "src")
+        files = files + sorted(p for p in glob.glob(os.path.join(vsrc, "*")) if os.path.isfile(p))
+    for path in files:
         h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
     h.update(" ".join(FLAGS).encode())

@@ -475,7 +475,13 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
                  flags | (DEBUG_CHECK_WINDOW if check_window else 0),
                  float(hint[0]) if spec else 0.0, float(hint[1]) if spec else 0.0, _stream(tgt_img))
     if check_window:
-        wrapped = int(outs[:n, 7].sum().item())  # (synchronises: a debugging mode)
+        wrapped_t = outs[:n, 7].sum().reshape(1)
+        if group is not None:
+            # every rank must take the same branch: a rank that raised alone would leave the others hanging in the
+            # all-reduce of the pair sums below (round-5 advisor finding)
+            import torch.distributed as dist
+            dist.all_reduce(wrapped_t, op=dist.ReduceOp.MAX, group=group)
+        wrapped = int(wrapped_t.item())  # (synchronises: a debugging mode)
         if wrapped:
             raise WindowOverflow(f"scsfm_hip: {wrapped} fixed-point cell(s) of the scatter window wrapped -- more than 32 "
                                  "near-cap pixels of one tile land on one reference pixel (an extremely compressive warp); "
@@ -572,8 +578,15 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
     else:
         lib.call(f"scsfm_pairs_bwd_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K), bflags, _p(scratch),
                  _p(g_photo), _p(g_geom), _stream(tgt_img))
-    if check_window:  # (debugging: the fallback geometry pass counts into the same words; synchronises)
+    if check_window:  # (debugging: the speculative tail counted into these words; synchronises)
         wrapped = sum(window_overflows(lib, ws, n, B, H, W, spec))
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # data parallel: every rank raises, or none -- a rank that raised alone would leave the others in the gradient
+            # all-reduce that follows this backward
+            t = torch.tensor([float(wrapped)], device=tgt_img.device if tgt_img.is_cuda else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wrapped = int(t.item())
         if wrapped:
             raise WindowOverflow(f"scsfm_hip: fixed-point cells of a scatter window wrapped {wrapped} time(s) in this step's "
                                  "forward / backward (an extremely compressive warp): depth gradients may be off")

@@ -53,3 +53,12 @@ def assert_close_frac(a, b, atol, rtol=0.0, max_bad_frac=0.0, what=""):
     bad = np.abs(a - b) > (atol + rtol * np.abs(b))
     frac = bad.mean() if bad.size else 0.0
     assert frac <= max_bad_frac, f"{what}: {bad.sum()} of {bad.size} entries differ (max |d|={np.abs(a-b).max():.3e})"
+
+
+REPORT_LINES = []
+
+
+def report(line):
+    """A line for the session's terminal summary (tests/conftest.py: pytest_terminal_summary)."""
+    REPORT_LINES.append(line)
+    print(line)

@@ -29,3 +29,14 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+# Lines the tests want in the session's summary whatever the capture mode (the driver keeps the tail of pytest's output):
+# tests/_util.report(line) collects, this hook prints.  Round 6: the entry-wise gradient judgement's judged shares and
+# HIP-worst / reference-worst ratios.
+def pytest_terminal_summary(terminalreporter):
+    from _util import REPORT_LINES
+    if REPORT_LINES:
+        terminalreporter.section("parity figures reported by the tests")
+        for line in REPORT_LINES:
+            terminalreporter.write_line(line)

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import assert_close_frac, load_inputs, load_npz
+from _util import assert_close_frac, load_inputs, load_npz, report
 
 pytestmark = pytest.mark.gpu
 
@@ -39,7 +39,11 @@ ENTRYWISE_MAX_FACTOR = {"smooth": 4.0, "iid": 4.0, "scene": 4.0}
 # of the coordinate flip them.  The margins now grow with the local slope of what is sampled
 # (oracle.pairwise_gate_margins: eps_slope_px); with them the same HIP gradients measure 1.2 / 2.0 / 1.2 x the reference
 # arithmetic's own worst entry on the three maps, and 81 .. 90 % of the iid entries are judged (91 .. 96 % elsewhere).
-ENTRYWISE_MIN_SHARE = {"smooth": 0.90, "iid": 0.78, "scene": 0.90}
+# Round 6: FROZEN (tests/test_oracle_golden.py::test_the_gate_margins_of_the_gradient_judgement_are_frozen holds the margins
+# and these constants); the iid share raised from 0.78 to what round 5 measured (0.81 .. 0.90) minus two points.
+ENTRYWISE_MIN_SHARE = {"smooth": 0.90, "iid": 0.79, "scene": 0.90}
+# error quantiles (median, 99 %, 99.9 %, 99.99 %) of the judged entries: HIP against the reference's fp32 arithmetic
+ENTRYWISE_QUANTILE_FACTORS = (2.0, 2.0, 2.0, 2.5)
 # test_iid_pose_gradients_as_row_statistics_over_seeds: HIP's row errors against the fp32 reference arithmetic's
 IID_ROW_FACTOR = 2.0
 FLAGS = [(1, 1, 1), (1, 1, 0), (1, 0, 1), (1, 0, 0), (0, 1, 1), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
@@ -806,9 +810,17 @@ def test_depth_gradients_entrywise_away_from_the_gates(LF, dev, B, depth, pad):
         eh, eo = ((a - c).abs() / scale)[keep], ((o - c).abs() / scale)[keep]
         q = lambda t: [float(torch.quantile(t[::3], p)) for p in (0.5, 0.99, 0.999, 0.9999)]
         qh, qo = q(eh), q(eo)
-        print(f"[{depth}/{pad}] map {i}: judged {share:.4f} of the entries; error / scale: hip median {qh[0]:.2e} p99 {qh[1]:.2e} "
-              f"p99.9 {qh[2]:.2e} p99.99 {qh[3]:.2e} max {float(eh.max()):.2e} | reference fp32 {qo[0]:.2e} {qo[1]:.2e} {qo[2]:.2e} {qo[3]:.2e} max {float(eo.max()):.2e} "
-              f"| set aside: hip max {float(((a - c).abs() / scale)[u].max()):.2e}")
+        # into the session's summary (the driver's log keeps it): judged share, HIP worst / reference-fp32 worst, the quantile
+        # ratios, and -- round-5 advisor -- the entries SET ASIDE are not unjudged altogether: their worst error is reported
+        # against the reference arithmetic's worst on the same set (both are off by up to a third of the scale there)
+        es_h, es_o = ((a - c).abs() / scale)[u], ((o - c).abs() / scale)[u]
+        report(f"entrywise [{depth}/{pad} B={B}] map {i}: judged {share:.4f}; worst hip {float(eh.max()):.2e} / ref-fp32 {float(eo.max()):.2e} = "
+               f"{float(eh.max()) / max(float(eo.max()), 1e-30):.2f}x; quantile ratios (50, 99, 99.9, 99.99 %) "
+               + " ".join(f"{x / max(y, 1e-30):.2f}" for x, y in zip(qh, qo))
+               + f"; set aside: worst hip {float(es_h.max()):.2e} / ref-fp32 {float(es_o.max()):.2e}, medians {float(es_h.median()):.2e} / {float(es_o.median()):.2e}")
+        # the set-aside entries: a genuine kernel error confined to them would show as a distribution wider than the
+        # reference arithmetic's own on the same set (3x on the median, a loose sanity bound)
+        assert float(es_h.median()) <= 3.0 * float(es_o.median()) + 1e-7, (i, float(es_h.median()), float(es_o.median()))
         assert share >= ENTRYWISE_MIN_SHARE[depth], (i, share)
         # the worst judged entry: no further from fp64 than ENTRYWISE_MAX_FACTOR x the worst entry of the reference's own
         # fp32 arithmetic in this very run (round 3 used constants: 3e-3, and 1e-1 on iid inputs)
@@ -816,7 +828,7 @@ def test_depth_gradients_entrywise_away_from_the_gates(LF, dev, B, depth, pad):
         # median, 99 %, 99.9 %: twice the reference arithmetic's; the 99.99 % quantile is the ~27th largest of the ~270 k sampled
         # entries -- a tail statistic: 2.5 x (measured over the four cases, session r05: 0.5 .. 2.0, the 2.0 on the
         # reference-1 map under border padding, whose worst entry is also the suite's largest at 2.9 x)
-        for x, y, f in zip(qh, qo, (2.0, 2.0, 2.0, 2.5)):
+        for x, y, f in zip(qh, qo, ENTRYWISE_QUANTILE_FACTORS):
             assert x <= f * y + 1e-7, (i, qh, qo)
 
 
@@ -920,6 +932,50 @@ def test_baseline_size_fixture_recorded_from_the_reference(LF, dev):
         for nm, t in ((f"g_pose{i}", ps[i]), (f"g_pose_inv{i}", pi[i])):
             want = z[nm].astype(np.float64)
             assert float(np.abs(t.grad.cpu().numpy() - want).max()) <= POSE_RTOL * float(np.abs(want).max()), nm
+
+
+def test_entrywise_against_the_references_own_fp32_gradients_at_baseline_size(LF, dev):
+    """Round-5 review: the entry-wise judgement above compares HIP with the ORACLE's fp32 run.  Here the comparand is the
+    unmodified reference's own fp32 gradients -- tests/golden/cfg1_reference.npz, every 191st entry of each depth gradient
+    of L = photo + 0.1 smooth + 0.5 geometry at 12 x 256 x 832, recorded by oracle/make_golden.py from the imported
+    reference -- under the same gate mask and the same bounds: errors against the fp64 oracle, HIP's worst judged entry
+    within ENTRYWISE_MAX_FACTOR x the reference's, median / 99 % / 99.9 % within 2 x."""
+    from oracle import scsfm_oracle as O
+    from scsfm_hip import synth
+    z = load_npz("cfg1_reference.npz")
+    d = synth.make_batch(12, 256, 832, n_ref=2, seed=101, depth="smooth", image="smooth", dataset="kitti")
+    chk = np.array([float(d["tgt_img"].double().sum()), float(d["tgt_depth"][0].double().sum()), float(d["poses"][0].double().sum())])
+    assert np.allclose(chk, z["input_check"], rtol=1e-12, atol=0), "the seeded inputs differ from the recorded ones"
+
+    def run(device, fns, dtype):
+        mv = lambda t: t.to(device=device, dtype=dtype).clone().requires_grad_(True)
+        cv = lambda t: t.to(device=device, dtype=dtype)
+        td, rd = [mv(d["tgt_depth"][0])], [[mv(r[0])] for r in d["ref_depths"]]
+        ps, pi = [mv(p) for p in d["poses"]], [mv(p) for p in d["poses_inv"]]
+        tgt, refs = cv(d["tgt_img"]), [cv(r) for r in d["ref_imgs"]]
+        photo, geom = fns[0](tgt, refs, cv(d["intrinsics"]), td, rd, ps, pi, 1, 1, 1, 1, "zeros")
+        smooth = fns[1](td, tgt, rd, refs)
+        (1.0 * photo + 0.1 * smooth + 0.5 * geom).backward()
+        return [g.grad.detach().cpu().double().reshape(-1) for g in td + [r[0] for r in rd]]
+
+    gh = run(dev, (LF.compute_photo_and_geometry_loss, LF.compute_smooth_loss), torch.float32)
+    g64 = run("cpu", (O.photo_and_geometry_loss, O.smooth_loss), torch.float64)
+    unsafe = _unsafe_maps(O, d, 2, "zeros")
+    for i, name in enumerate(("g_tgt_depth", "g_ref0_depth", "g_ref1_depth")):
+        ref32 = torch.from_numpy(z[f"{name}/sample191"].astype(np.float64))
+        a, c, keep = gh[i][::191], g64[i][::191], ~unsafe[i].reshape(-1)[::191]
+        scale = float(g64[i].abs().max())
+        eh, eo = ((a - c).abs() / scale)[keep], ((ref32 - c).abs() / scale)[keep]
+        q = lambda t: [float(torch.quantile(t, p)) for p in (0.5, 0.99, 0.999)]
+        qh, qo = q(eh), q(eo)
+        share = float(keep.double().mean())
+        report(f"entrywise vs the REFERENCE's recorded fp32 gradients [cfg1, every 191st entry] {name}: judged {share:.4f} of {keep.numel()}; "
+               f"worst hip {float(eh.max()):.2e} / reference {float(eo.max()):.2e} = {float(eh.max()) / max(float(eo.max()), 1e-30):.2f}x; "
+               "quantile ratios (50, 99, 99.9 %) " + " ".join(f"{x / max(y, 1e-30):.2f}" for x, y in zip(qh, qo)))
+        assert share >= ENTRYWISE_MIN_SHARE["smooth"], (name, share)
+        assert float(eh.max()) <= ENTRYWISE_MAX_FACTOR["smooth"] * float(eo.max()) + 1e-6, (name, float(eh.max()), float(eo.max()))
+        for x, y, f in zip(qh, qo, ENTRYWISE_QUANTILE_FACTORS):
+            assert x <= f * y + 1e-7, (name, qh, qo)
 
 
 def test_inputs_at_odd_element_offsets_give_the_same_results(dev, LF):

@@ -146,5 +146,31 @@ def test_oracle_reproduces_the_reference_at_baseline_size():
         want = z[f"{name}/checks"]
         assert abs(float(g.sum()) - want[0]) <= 1e-5 * want[1] and abs(float(g.abs().sum()) - want[1]) <= 1e-5 * want[1], name
         assert np.allclose(t.grad.reshape(-1)[::997].numpy(), z[f"{name}/sample"], rtol=1e-3, atol=1e-6 * want[4]), name
+        # round 6: the denser sample of the reference's own gradients (the comparand of the GPU suite's entry-wise judgement)
+        assert np.allclose(t.grad.reshape(-1)[::191].numpy(), z[f"{name}/sample191"], rtol=1e-3, atol=1e-6 * want[4]), name
     for i in range(2):
         assert np.allclose(ps[i].grad.numpy(), z[f"g_pose{i}"], rtol=1e-3, atol=1e-4 * np.abs(z[f"g_pose{i}"]).max())
+
+
+def test_the_gate_margins_of_the_gradient_judgement_are_frozen():
+    """Round-5 review: the entry-wise gradient judgement of tests/test_gpu_parity.py sets aside the entries whose value can
+    hinge on a gate decided within fp32 round-off (oracle.pairwise_gate_margins).  Its three margins were widened once
+    (round 5: eps_slope_px introduced, with the root-cause analysis of profiles/r05_iid_worst_entries.json); they are
+    frozen here -- a further widening is a change of the parity criterion and has to show up as an edit of THIS test --
+    together with the shares of entries that must remain judged and the bounds they are held to."""
+    import inspect
+    from oracle import scsfm_oracle as O
+    sig = inspect.signature(O.pairwise_gate_margins)
+    assert {k: sig.parameters[k].default for k in ("eps_px", "eps_val", "eps_slope_px")} == \
+        {"eps_px": 2e-3, "eps_val": 2e-4, "eps_slope_px": 5e-4}
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("_gpu_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_parity.py"))
+    src = open(spec.origin).read()
+    ns = {}
+    for line in src.split("\n"):
+        if line.startswith(("ENTRYWISE_MAX_FACTOR =", "ENTRYWISE_MIN_SHARE =", "ENTRYWISE_QUANTILE_FACTORS =")):
+            exec(line, ns)
+    assert ns["ENTRYWISE_MAX_FACTOR"] == {"smooth": 4.0, "iid": 4.0, "scene": 4.0}
+    assert ns["ENTRYWISE_MIN_SHARE"] == {"smooth": 0.90, "iid": 0.79, "scene": 0.90}
+    assert ns["ENTRYWISE_QUANTILE_FACTORS"] == (2.0, 2.0, 2.0, 2.5)
