@@ -117,13 +117,18 @@ def pmc_traffic(args, n_pairs, lib_source_id):
         cal_path = os.path.join(ROOT, "profiles", "r06_fetch_calibration.json")
         if os.path.exists(cal_path):
             cal = json.load(open(cal_path)).get("kernels", {})
-            # the kernel's reads are 4-byte coalesced rows and 8-byte gathers, its writes 4-byte rows and float atomics
-            f = [v["FETCH_SIZE_over_known"] for n, v in cal.items() if ("read_kernel<unsigned int>" in n or "gather_b64" in n) and "FETCH_SIZE_over_known" in v]
+            # measured with known-bytes kernels (tools/ubench/fetch_calib.hip, profiles/r06_fetch_calibration.json): FETCH_SIZE
+            # counts HALF the bytes of coalesced reads (4, 8 and 16 bytes per lane alike) and ALL bytes of 8-byte gathers;
+            # WRITE_SIZE counts all bytes of stores and of float atomics.  The kernel mixes coalesced rows and gathers, so
+            # its true fetch lies between the raw counter (all gathers) and twice it (all coalesced rows)
+            f = {n: v["FETCH_SIZE_over_known"] for n, v in cal.items() if ("read_kernel<unsigned int>" in n or "gather_b64" in n) and "FETCH_SIZE_over_known" in v}
             w = [v["WRITE_SIZE_over_known"] for n, v in cal.items() if ("write_kernel<unsigned int>" in n or "atomic_f32" in n) and "WRITE_SIZE_over_known" in v]
-            if f and w:
-                out["fetch_counter_per_known_byte"] = round(sum(f) / len(f), 4)
+            if len(f) == 2 and w:
+                lo, hi = min(f.values()), max(f.values())
+                out["fetch_counter_per_known_byte"] = {"coalesced_b32": [v for n, v in f.items() if "read_kernel" in n][0],
+                                                       "gather_b64": [v for n, v in f.items() if "gather" in n][0]}
                 out["write_counter_per_known_byte"] = round(sum(w) / len(w), 4)
-                out["fetch_bytes"] = int(out["fetch_bytes_raw"] / (sum(f) / len(f)))
+                out["fetch_bytes_range"] = [int(out["fetch_bytes_raw"] / hi), int(out["fetch_bytes_raw"] / lo)]
                 out["write_bytes"] = int(out["write_bytes_raw"] / (sum(w) / len(w)))
                 out["calibration"] = "profiles/r06_fetch_calibration.json"
         return out, "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_round.sh on this library): QUOTED, not measured in this run"

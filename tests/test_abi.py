@@ -113,7 +113,14 @@ def test_bench_quotes_hbm_counters_only_for_the_library_they_were_collected_on(t
     json.dump({"_library_source_id": "aaaa", key: {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 24.0}}, open(prof / "pmc_latest.json", "w"))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     a = argparse.Namespace(batch=12, height=256, width=832, n_ref=2, depth="smooth")
-    assert bench.pmc_traffic(a, 4, "aaaa")[0] == 1024 * 1024
+    t, why = bench.pmc_traffic(a, 4, "aaaa")
+    # the two counters separately (round 6), raw; and calibrated where profiles/r06_fetch_calibration.json is there
+    assert t["fetch_bytes_raw"] == 1000 * 1024 and t["write_bytes_raw"] == 24 * 1024 and "QUOTED" in why and "fetch_bytes" not in t
+    json.dump({"kernels": {"read_kernel<unsigned int>": {"FETCH_SIZE_over_known": 0.5}, "gather_b64_kernel": {"FETCH_SIZE_over_known": 1.0},
+                           "write_kernel<unsigned int>": {"WRITE_SIZE_over_known": 1.0}, "atomic_f32_kernel": {"WRITE_SIZE_over_known": 1.0}}},
+              open(prof / "r06_fetch_calibration.json", "w"))
+    t, _ = bench.pmc_traffic(a, 4, "aaaa")
+    assert t["fetch_bytes_range"] == [1000 * 1024, 2000 * 1024] and t["write_bytes"] == 24 * 1024
     got, why = bench.pmc_traffic(a, 4, "bbbb")
     assert got is None and "aaaa" in why and "bbbb" in why
     a.depth = "iid"

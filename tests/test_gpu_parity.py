@@ -447,6 +447,38 @@ def test_compressive_warps_do_not_wrap_the_fixed_point_window(dev, B, scale, tz,
         assert _rel64(g_td[0].double(), td64[0].grad) < 1e-4, check
 
 
+@pytest.mark.parametrize("auto", [0, 1])
+def test_nonuniform_compression_inside_a_large_footprint(dev, auto):
+    """Twin of tests/test_hostsim_kernels.py::test_nonuniform_compression_inside_a_large_footprint_fp32 on the hardware
+    (round-5 review item 4): every other column of a tile very near (depth << the forward motion: those pixels collapse
+    onto a few texels, unscaled scatter terms ~25 each), the rest far (spread over hundreds of cells) -- a compression the
+    bounding-box heuristic of round 5 could not see; photo-only upstream gradient.  The unit of the tile's fixed-point cells
+    follows from the per-tile bound (csrc/scsfm_geom.h: win_units_of): no wrap in the debug launch (exact count) nor in
+    the product launch, dL/d ref_depth within 1e-4 of the fp64 oracle."""
+    from _util import nonuniform_case as _nonuniform_case
+    from oracle import scsfm_oracle as O
+    from scsfm_hip import _lib, capi
+    lib = _lib.get()
+    ti, K, ris, tds, rds, ps, pis = _nonuniform_case()
+    c = lambda x: x.double()
+    lf = lambda x: x.double().clone().requires_grad_(True)
+    td64, rd64 = [lf(tds[0])], [[lf(rds[0][0])]]
+    po, go = O.photo_and_geometry_loss(c(ti), [c(ris[0])], c(K), td64, rd64, [c(ps[0])], [c(pis[0])], 1, 1, 1, auto, "zeros")
+    po.backward()
+    fl = capi.make_flags(1, 1, auto, "zeros")
+    v = lambda x: x.to(dev).contiguous()
+    a = (v(ti), v(K), [v(ris[0])], [v(tds[0])], [[v(rds[0][0])]], [v(ps[0])], [v(pis[0])])
+    t = lambda x: torch.tensor([x], device=dev)
+    for check in (True, False):
+        photo, geom, outs, ws = capi.photo_geometry_fwd(lib, fl, *a, hint=(1.0, 0.0), check_window=check)
+        assert abs(float(photo) - float(po)) < 1e-5 and abs(float(geom) - float(go)) < 1e-5
+        g_td, g_rd, _, _ = capi.photo_geometry_bwd(lib, fl, *a, ws, t(1.0), t(0.0), check_window=check)
+        assert capi.window_overflows(lib, ws, 2, 2, 72, 100) == [0, 0]
+        assert float(rd64[0][0].grad.abs().max()) * 3 * float(outs[0, 4]) > 2048  # beyond a 2^-20 cell's range on the busiest texel
+        assert _rel64(g_rd[0][0].double(), rd64[0][0].grad) < 1e-4, check
+        assert _rel64(g_td[0].double(), td64[0].grad) < 1e-4, check
+
+
 @pytest.mark.parametrize("depth", ["smooth", "iid", "scene"])
 def test_no_window_cell_wraps_on_the_bench_inputs(LF, dev, depth, monkeypatch):
     """The exact wrap detector (SCSFM_CHECK_WINDOW=1: returning LDS atomics in the speculative forward and in the fallback

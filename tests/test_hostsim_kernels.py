@@ -537,24 +537,7 @@ def test_compressive_warps_do_not_wrap_the_fixed_point_window_fp32(lib, B, scale
     assert _rel(g_rd[0][0].double(), rd64[0][0].grad) < 1e-4 and _rel(g_td[0].double(), td64[0].grad) < 1e-4
 
 
-def _nonuniform_case(B=2, seed=71):
-    """Round-5 review: a NON-uniform compression inside a large footprint, which the bounding-box heuristic of round 5
-    could not see.  Forward motion tz; the left half of every row is very near (depth << tz: those pixels collapse onto
-    a few texels around the principal point, their unscaled scatter terms 2 Z / (Z + D_p)^2 ~ 25 each), the right half is
-    far (depth >> tz: they stay where they are and spread over hundreds of cells).  Photo-only upstream gradient: all
-    terms of one sign."""
-    H, W = 72, 100
-    d = synth.make_batch(B, H, W, n_ref=1, seed=seed, depth="smooth")
-    g = torch.Generator().manual_seed(9)
-    tz = 0.06
-    near = 0.002 + 0.002 * torch.rand(B, 1, H, W, generator=g)
-    far = 5.0 + 2.0 * torch.rand(B, 1, H, W, generator=g)
-    left = (torch.arange(W) % 2 == 0).view(1, 1, 1, W)  # alternate columns: every tile holds both kinds
-    tds = [torch.where(left, near, far).contiguous()]
-    rds = [[(0.004 + 0.004 * torch.rand(B, 1, H, W, generator=g)).contiguous()]]
-    p = torch.zeros(B, 6)
-    p[:, 2] = tz
-    return d["tgt_img"], d["intrinsics"], d["ref_imgs"], tds, rds, [p], [-p.clone()]
+from _util import nonuniform_case as _nonuniform_case  # noqa: E402  (shared with the hardware twin in tests/test_gpu_parity.py)
 
 
 @pytest.mark.parametrize("auto", [0, 1])
