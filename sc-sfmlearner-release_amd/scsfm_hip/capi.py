@@ -465,7 +465,8 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
             d.smooth_out = souts.data_ptr() + f * souts.element_size()
     if smooth:
         assert len(seen) == nf
-    if smooth and step is not None:
+    MAX_PAIRS_PER_LAUNCH = 8  # (csrc: kMaxPairs; scsfm_pairs_fwd_step forms the total in ONE finalize launch)
+    if smooth and step is not None and n <= MAX_PAIRS_PER_LAUNCH:
         step_out = torch.empty(4, dtype=tgt_img.dtype, device=tgt_img.device)
         lib.call(f"scsfm_pairs_fwd_step_{_suffix(tgt_img)}", n, _ct.addressof(descs), B, H, W, _p(K),
                  flags | (DEBUG_CHECK_WINDOW if check_window else 0), float(step[0]), float(step[1]), float(step[2]),
@@ -493,6 +494,9 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
         outs[:n, 2:5] = sums
         for j in range(n):
             pair_refinalize(lib, (B, H, W), ws[j * stride:j * stride + ws_bytes], outs[j])
+    if smooth and step is not None and step_out is None:
+        # more pair-directions than one launch holds (several scales): the weighted sum in a launch of its own
+        step_out = step_total(lib, outs[n, :2], souts[nf:nf + 1], *step)
     extra = () if not smooth else ((souts[nf], sws) if step is None else (souts[nf], sws, step_out))
     if flags & 16384:  # SCSFM_DEBUG_KERNEL_ONLY (bench.py): nothing was finalised
         return (None, None, outs[:n], ws) + extra

@@ -35,10 +35,16 @@ def _scalar(g, like):
 # ------------------------------------------------------------------------------------------------
 class _SmoothStash:
     """What the speculative forward of compute_photo_and_geometry_loss left for the compute_smooth_loss call that
-    train.py:262-266 makes next on the SAME frames: the loss, and the smooth workspace the backward needs.  Keyed on the
-    identity of the tensor OBJECTS (weak references: a new tensor at a recycled address is another object) and their
-    version counters (an in-place write in between invalidates the entry); consumed by the first matching call, replaced
-    by the next forward.  A miss costs nothing but the stand-alone smooth forward."""
+    train.py:262-266 makes next on the SAME frames: the smooth loss as a THIRD OUTPUT of the PhotoGeometryLoss node
+    (loss_functions.compute_photo_and_geometry_loss hands the caller the first two, as the reference does, and parks the
+    third here).  compute_smooth_loss returns that very tensor: its gradient then arrives in the same backward call as
+    the pair losses' and the smooth term's depth gradients are added by the combining pass that stores theirs
+    (scsfm_pairs_bwd_smooth) -- no smooth backward launch, no second gradient per depth map for autograd to add.
+    Autograd-correct for every use: a caller who differentiates only one of the losses gets None for the others'
+    upstream gradients, which count as zero.  Keyed on the identity of the tensor OBJECTS (weak references: a new
+    tensor at a recycled address is another object) and their version counters (an in-place write in between invalidates
+    the entry); consumed by the first matching call, replaced by the next forward.  A miss costs nothing but the
+    stand-alone smooth forward."""
     slot = None
 
     @staticmethod
@@ -46,22 +52,22 @@ class _SmoothStash:
         return [(weakref.ref(t), t._version) for t in list(depths) + list(imgs)]
 
     @classmethod
-    def put(cls, depths, imgs, loss, sws, keep_edges):
-        cls.slot = (cls.key(depths, imgs), loss, sws, keep_edges, _stream_id(imgs[0]))
+    def put(cls, depths, imgs, loss):
+        cls.slot = (cls.key(depths, imgs), loss, _stream_id(imgs[0]), torch.is_grad_enabled())
 
     @classmethod
-    def take(cls, depths, imgs, keep_edges):
+    def take(cls, depths, imgs):
         slot, cls.slot = cls.slot, None
         if slot is None:
             return None
-        keys, loss, sws, kept, stream = slot
+        keys, loss, stream, grad_mode = slot
         ts = list(depths) + list(imgs)
-        if len(keys) != len(ts) or (keep_edges and not kept) or stream != _stream_id(imgs[0]):
+        if len(keys) != len(ts) or stream != _stream_id(imgs[0]) or grad_mode != torch.is_grad_enabled():
             return None
         for (ref, ver), t in zip(keys, ts):
             if ref() is not t or t._version != ver:
                 return None
-        return loss, sws
+        return loss
 
 
 def _stream_id(t):
@@ -70,7 +76,10 @@ def _stream_id(t):
 
 class PhotoGeometryLoss(torch.autograd.Function):
     """forward(flags, n_ref, n_scales, tgt_img, K, *ref_imgs, *tgt_depths, *ref_depths, *poses,
-    *poses_inv) -> (photo_loss, geometry_loss)
+    *poses_inv) -> (photo_loss, geometry_loss, smooth_loss | None)
+
+    The third output (round 6): compute_smooth_loss of the frames [tgt, refs...] at scale 0, evaluated by the speculative
+    forward on the way (scsfm_pair_desc::smooth_ws) whenever it speculates on full-resolution maps; None otherwise.
 
     Depth maps are full resolution (scale s > 0 is nearest-upsampled by the caller, under
     autograd).  ref_depths is flattened ref-major: ref_depths[i * n_scales + s].
@@ -91,8 +100,6 @@ class PhotoGeometryLoss(torch.autograd.Function):
     def forward(ctx, flags, n_ref, n_scales, tgt_img, K, *rest):
         from . import config as _config, dist as _dist
         lib = _lib.get()
-        orig_ref_imgs, orig_depths, orig_ref_depths, _, _, _ = PhotoGeometryLoss._split(list(rest), n_ref, n_scales)
-        orig_tgt_img = tgt_img
         rest = [_c(t) for t in rest]
         tgt_img, K = _c(tgt_img), _c(K)
         _need_cuda(tgt_img, K, *rest)
@@ -101,23 +108,22 @@ class PhotoGeometryLoss(torch.autograd.Function):
         hint = _config.weight_hint() if any(ctx.needs_input_grad) else None
         # the pair the kernels speculate on lives on the device: every backward leaves the upstream gradients it saw there
         hint_dev = _config.hint_tensor(tgt_img.device) if hint is not None else None
-        # the smooth loss of the same frames (the call train.py:262-266 makes next) rides in the speculative tiles and
-        # waits in the stash: identity of the ORIGINAL tensor objects, which is what compute_smooth_loss will be handed
+        # the smooth loss of the same frames (the call train.py:262-266 makes next) rides in the speculative tiles
         ride = _config.smooth_rides_along() and capi.smooth_rides_along(flags, tgt_img, tgt_depths, ref_depths, hint)
         res = capi.photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses,
                                       poses_inv, group=_dist.exact_group(), hint=hint, hint_dev=hint_dev,
                                       check_window=hint is not None and _config.check_window(), smooth=ride)
         photo, geom, _, ws = res[:4]
-        if ride:
-            frames = [orig_depths[0]] + [orig_ref_depths[i][0] for i in range(n_ref)]
-            _SmoothStash.put(frames, [orig_tgt_img] + orig_ref_imgs, res[4], res[5], True)
+        smooth, sws = (res[4], res[5]) if ride else (None, None)
         ctx.flags, ctx.n_ref, ctx.n_scales = flags, n_ref, n_scales
         ctx.hint_dev = hint_dev
-        ctx.save_for_backward(tgt_img, K, *rest, ws)
-        return photo, geom
+        ctx.rides = ride
+        ctx.set_materialize_grads(False)  # an output nobody differentiates arrives as None, not as a zero tensor
+        ctx.save_for_backward(tgt_img, K, *rest, ws, *([sws] if ride else []))
+        return photo, geom, smooth
 
     @staticmethod
-    def backward(ctx, g_photo, g_geom):
+    def backward(ctx, g_photo, g_geom, g_smooth=None):
         from . import config as _config
         lib = _lib.get()
         n_ref, n_scales, flags = ctx.n_ref, ctx.n_scales, ctx.flags
@@ -125,6 +131,9 @@ class PhotoGeometryLoss(torch.autograd.Function):
         tgt_img, K = saved[0], saved[1]
         ref_imgs, tgt_depths, ref_depths, poses, poses_inv, n_in = PhotoGeometryLoss._split(saved[2:], n_ref, n_scales)
         ws = saved[2 + n_in]
+        # the smooth loss of this node was used (compute_smooth_loss found it in the stash): its depth gradients ride in
+        # the combining pass of the pair terms
+        smooth = (saved[3 + n_in], _scalar(g_smooth, tgt_img)) if (ctx.rides and g_smooth is not None) else None
         # images and intrinsics are data to train.py; the reference's autograd reaches them all the same, and so does
         # this node when asked (one extra tiled pass for the images, a reduction for K)
         need_imgs = [ctx.needs_input_grad[3]] + list(ctx.needs_input_grad[5:5 + n_ref])
@@ -132,9 +141,12 @@ class PhotoGeometryLoss(torch.autograd.Function):
         res = capi.photo_geometry_bwd(
             lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths, poses, poses_inv, ws,
             _scalar(g_photo, tgt_img), _scalar(g_geom, tgt_img), hint_dev=ctx.hint_dev,
-            need_imgs=need_imgs if any(need_imgs) else None, need_K=need_K, check_window=_config.check_window())
+            need_imgs=need_imgs if any(need_imgs) else None, need_K=need_K, smooth=smooth, check_window=_config.check_window())
         g_td, g_rd, g_poses, g_poses_inv = res[:4]
         g_imgs, g_K = res[4:] if len(res) > 4 else ([None] * (1 + n_ref), None)
+        if smooth is not None and any(need_imgs):  # (the data inputs: the smooth term reaches the images through its edge weights)
+            frames = [tgt_depths[0]] + [r[0] for r in ref_depths]
+            capi.smooth_multi_bwd_images(lib, frames, [tgt_img] + list(ref_imgs), smooth[0], smooth[1], need_imgs, into=g_imgs)
         return (None, None, None, g_imgs[0], g_K, *g_imgs[1:], *g_td, *[g for r in g_rd for g in r], *g_poses,
                 *g_poses_inv)
 
@@ -176,14 +188,10 @@ class SmoothLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, n, *rest):
         lib = _lib.get()
-        orig = list(rest)
         rest = [_c(t) for t in rest]
         _need_cuda(*rest)
         depths, imgs = rest[:n], rest[n:]
-        keep = any(ctx.needs_input_grad[1:1 + n])
-        # (autograd hands forward() the caller's tensor objects: the stash is keyed on them)
-        hit = _SmoothStash.take(orig[:n], orig[n:], keep)
-        loss, ws = hit if hit is not None else capi.smooth_multi_fwd(lib, depths, imgs, keep_edges=keep)
+        loss, ws = capi.smooth_multi_fwd(lib, depths, imgs, keep_edges=any(ctx.needs_input_grad[1:1 + n]))
         ctx.n = n
         ctx.save_for_backward(*rest, ws)
         return loss
