@@ -303,6 +303,7 @@ def cpu_baseline(args, budget_s):
     variants = list(dict.fromkeys(variants))
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--impl", "reference" if kind == "reference" else "oracle",
            "--variants", ",".join(f"{t}:{b}:{a}" for t, b, a in variants), "--seconds", str(budget_s), "--min-steps", "15",
+           "--e2e-configs0", "1" if (args.height, args.width, args.n_ref, args.dataset) == (256, 832, 2, "kitti") else "0",
            "--height", str(args.height), "--width", str(args.width), "--n-ref", str(args.n_ref), "--depth", args.depth,
            "--dataset", args.dataset]
     env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH",)}
@@ -311,6 +312,8 @@ def cpu_baseline(args, budget_s):
     if out.returncode != 0:
         raise RuntimeError("cpu baseline failed: " + out.stderr[-2000:])
     rows = json.loads(out.stdout.strip().split("\n")[-1])
+    e2e0 = [r for r in rows if r.get("configs0_end_to_end")]
+    rows = [r for r in rows if not r.get("configs0_end_to_end")]
     head = max((r for r in rows if r["batch"] == b_gpu and not r["anomaly_mode"]), key=lambda r: r["images_per_sec"])
     n_px = head["batch"] * args.height * args.width
     return {"value": head["images_per_sec"], "unit": "images/s (loss path only, fwd+bwd)", "cores": head["threads"], "kind": kind,
@@ -323,7 +326,9 @@ def cpu_baseline(args, budget_s):
             "ms_per_step": head["ms_per_step"], "min_ms_per_step": head.get("min_ms_per_step"),
             "block_medians_ms": head.get("block_medians_ms"), "last_two_blocks_differ_by": head.get("last_two_blocks_differ_by"),
             "algorithmic_GBs": round(step_bytes(n_px, args.n_ref) / (head["ms_per_step"] * 1e-3) / 1e9, 3),
-            "host_cores_available": avail, "variants": rows}
+            "host_cores_available": avail, "variants": rows,
+            # BASELINE.json configs[0] end to end on the host (nets + loss + Adam, batch 4): context for `value`
+            "configs0_end_to_end": e2e0[0] if e2e0 else None}
 
 
 def library_identity(lib):

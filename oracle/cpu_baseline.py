@@ -121,6 +121,8 @@ def run_one(args, threads, batch, anomaly, budget):
     torch.autograd.set_detect_anomaly(bool(anomaly))
     d = synth.make_batch(batch, args.height, args.width, n_ref=args.n_ref, seed=0, depth=args.depth,
                          image="smooth" if args.depth == "smooth" else "iid", dataset=args.dataset)
+    if args.e2e:
+        return run_e2e(args, torch, d, step, threads, batch, budget, cores)
 
     def one():
         lf = lambda t: t.clone().requires_grad_(True)
@@ -162,6 +164,45 @@ def run_one(args, threads, batch, anomaly, budget):
             "pinned_to_cpus": cores, "omp_proc_bind": os.environ.get("OMP_PROC_BIND"), "loss": loss}
 
 
+def run_e2e(args, torch, d, loss_step, threads, batch, budget, cores):
+    """BASELINE.json configs[0] END TO END on host cores (last bullet): what train.py:249-286 does per
+    iteration -- DispResNet18 on the three frames, PoseResNet18 on the four ordered pairs, the loss (the unmodified reference
+    or its ATen-mode restatement, as above), backward, Adam -- random-init nets (--with-pretrain 0), batch 4.  The nets are
+    this repo's plain-torch models (the reference's need torchvision, which is not installed; same layers and state-dict
+    keys: tests/test_models_vs_reference.py).  A few steps only: one takes seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "sc-sfmlearner-release_amd"))
+    import models
+    torch.manual_seed(0)
+    disp_net, pose_net = models.DispResNet(18, False).train(), models.PoseResNet(18, False).train()
+    opt = torch.optim.Adam([{"params": disp_net.parameters()}, {"params": pose_net.parameters()}], lr=1e-4, betas=(0.9, 0.999))
+    tgt, refs, K = d["tgt_img"], d["ref_imgs"], d["intrinsics"]
+
+    def one():
+        tgt_depth = [1 / disp for disp in disp_net(tgt)]
+        ref_depths = [[1 / disp for disp in disp_net(r)] for r in refs]
+        poses = [pose_net(tgt, r) for r in refs]
+        poses_inv = [pose_net(r, tgt) for r in refs]
+        photo, smooth, geom = loss_step(d, tgt_depth[:1], [r[:1] for r in ref_depths], poses, poses_inv)
+        loss = W_PHOTO * photo + W_SMOOTH * smooth + W_GEOM * geom
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    one()  # warm-up
+    times, t_start = [], time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_start < budget and len(times) < 8):
+        t0 = time.perf_counter()
+        loss = one()
+        times.append(time.perf_counter() - t0)
+    m = sorted(times)[len(times) // 2]
+    return {"configs0_end_to_end": True, "threads": threads, "batch": batch, "anomaly_mode": False,
+            "ms_per_step": round(m * 1e3, 1), "min_ms_per_step": round(min(times) * 1e3, 1), "images_per_sec": round(batch / m, 3),
+            "timed_steps": len(times), "pinned_to_cpus": cores, "omp_proc_bind": os.environ.get("OMP_PROC_BIND"), "loss": loss,
+            "what": "DispResNet18 + PoseResNet18 forward/backward (plain torch), the loss path, Adam: one training iteration of "
+                    "train.py:249-286 on host cores, random-init nets, synthetic batch"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--impl", choices=["reference", "oracle"], required=True)
@@ -174,6 +215,9 @@ def main():
     ap.add_argument("--n-ref", type=int, default=2)
     ap.add_argument("--depth", default="smooth")
     ap.add_argument("--dataset", default="kitti")
+    ap.add_argument("--e2e-configs0", type=int, default=0, help="1: also one variant that runs configs[0] END TO END (nets + "
+                                                                "loss + Adam, batch 4) on the first variant's thread count")
+    ap.add_argument("--e2e", type=int, default=0, help="(internal) --one runs the end-to-end step")
     ap.add_argument("--one", default=None, help="(internal) run this single variant in this process")
     ap.add_argument("--budget", type=float, default=0.0, help="(internal) seconds for --one")
     args = ap.parse_args()
@@ -198,6 +242,18 @@ def main():
             sys.stderr.write(r.stderr[-3000:])
             sys.exit(r.returncode)
         out.append(json.loads(r.stdout.strip().split("\n")[-1]))
+    if args.e2e_configs0:
+        threads = variants[0][0]
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
+        cmd = [sys.executable, os.path.abspath(__file__), "--impl", args.impl, "--ref-dir", args.ref_dir, "--variants", "-",
+               "--one", f"{threads}:4:0", "--e2e", "1", "--budget", str(max(10.0, 0.5 * args.seconds)),
+               "--height", str(args.height), "--width", str(args.width), "--n-ref", str(args.n_ref), "--depth", args.depth,
+               "--dataset", args.dataset]
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        if r.returncode == 0:
+            out.append(json.loads(r.stdout.strip().split("\n")[-1]))
+        else:  # (reported, not fatal: the headline rows above stand)
+            out.append({"configs0_end_to_end": True, "error": r.stderr[-600:]})
     print(json.dumps(out))
 
 
