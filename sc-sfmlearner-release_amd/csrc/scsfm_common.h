@@ -51,9 +51,8 @@ struct BatchConsts {
 //                                 reduced by pose_reduce_bwd_kernel -- same-address atomics from ~200 blocks per
 //                                 image cost 60 us per launch, partials cost nothing)
 //   [off_partials]     partials : double[nblocks][3]
-//   [off_smooth]       smooth   : double[nblocks][waves per block][3] = {sum D, Sx, Sy} of the target frame's smooth loss, one
-//                                 record per wave of every tile (only written by a speculative forward whose descriptor
-//                                 names a smooth workspace)
+//   [off_smooth]       smooth   : double[nblocks][3] = {sum D, Sx, Sy} of the target frame's smooth loss per tile (only
+//                                 written by a speculative forward whose descriptor names a smooth workspace)
 struct PairWs {
   size_t off_sums, off_gP, off_partials, off_smooth, total;
   int nbx, nby;
@@ -87,7 +86,7 @@ inline PairWs pair_ws_layout(int B, int H, int W) {
   // 60-column strips of the speculative forward)
   l.off_partials = off; off += (size_t)ceil_div(W, kTileW - 4) * ceil_div(H, 6) * B * 3 * sizeof(double);
   // the target frame's smooth-loss partials of a pair that carries them (scsfm_pair_desc::smooth_ws): one record per tile
-  l.off_smooth = off; off += (size_t)ceil_div(W, kTileW - 4) * ceil_div(H, 6) * B * 3 * (kThreads / kWave) * sizeof(double);
+  l.off_smooth = off; off += (size_t)ceil_div(W, kTileW - 4) * ceil_div(H, 6) * B * 3 * sizeof(double);
   l.total = (off + 255) & ~(size_t)255;
   return l;
 }

@@ -331,13 +331,12 @@ __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb
     // wave reduces whole images with shuffles, in a fixed order, then the waves' contributions meet in LDS)
     __shared__ double sm_red[kThreads / kWave];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, B = nblocks / nblk_img;
-    const int nrec = nblk_img * (kThreads / kWave);  // one record per wave of every tile of an image
+    const int nrec = nblk_img;  // one record per tile of an image
     const double cnt_x = (double)B * H * (W - 1), cnt_y = (double)B * (H - 1) * W;
     double loss = 0.0;
     for (int b = wave; b < B; b += kThreads / kWave) {
       double v0 = 0, v1 = 0, v2 = 0;
-      // (eight records per lane in flight: the 1064 records of a 256 x 832 image are three L2 round trips per image, not
-      // nine -- with two in flight this loop cost the finalize launch 15 us)
+      // (several records per lane in flight: the 266 records of a 256 x 832 image are ONE L2 round trip per image)
       constexpr int U8 = 8;
       for (int i0 = lane; i0 < nrec; i0 += U8 * kWave) {
         double q[U8][3];

@@ -31,22 +31,6 @@ __device__ __forceinline__ void sched_fence() {
 #define SCSFM_STAGE_TAPS 1
 #endif
 
-// The smooth loss of a tile's target frame (scsfm_pair_desc::smooth_ws): the strip's part of the three sums and of the
-// edge plane (scsfm_smooth_math.h), then one record {sum D, Sx, Sy} per WAVE: pa.sm_partials[(tile * waves + wave) * 3 ..].
-template <typename T, int STRIP>
-__device__ __forceinline__ void smooth_tile_part(const PairArgs<T>& pa, const Px<T> (&row)[STRIP], const Px<T>& up, const Px<T>& dn,
-                                                 int px, int py0, bool in_x, const bool (&own_row)[STRIP], T icx, T icy, int H,
-                                                 int W, int b, unsigned plane, int wave, int lane, size_t tile) {
-  T sm[3] = {T(0), T(0), T(0)};
-  smooth_strip<T, STRIP>(row, up, dn, px, py0, in_x, own_row, icx, icy, H, W, pa.sm_edge ? pa.sm_edge + (size_t)b * plane : nullptr, sm);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) sm[i] = wave_sum_last(sm[i]);
-  if (lane == kWave - 1) {
-    double* o = pa.sm_partials + 3 * (tile * (kThreads / kWave) + wave);
-    o[0] = double(sm[0]); o[1] = double(sm[1]); o[2] = double(sm[2]);
-  }
-}
-
 template <typename T, bool kSsim, bool kScaled, unsigned kFlags, bool kStageFwd = false>
 // (kSpec: always true here -- the backward's own tiled pass is photo_tile in scsfm_pair.hip)
 __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, const PairBatch<T>& pb, int B, int H,
@@ -119,6 +103,8 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
   T acc_g = T(0), acc_m = T(0);  // kSpec: forward sums over the pixels this block owns
   int bx0 = 1 << 30, bx1 = -(1 << 30), by0 = 1 << 30, by1 = -(1 << 30);
   __shared__ int sBox[kSpec ? kThreads / kWave : 1][4];
+  // pairs that carry their target frame's smooth loss (pa.sm_partials; uniform per pair): the waves' three sums
+  __shared__ T sSm[kThreads / kWave][4];
   // fixed-point scatter cells: the bound of what this tile can add to one of them (scsfm_geom.h: win_units_of)
   constexpr bool kFixed = sizeof(typename WinCell<T>::type) == 4 && sizeof(T) == 4;
   __shared__ float sU[kThreads / kWave];
@@ -172,14 +158,11 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     }
     // ---- the target frame's smooth loss (loss_functions.py:133-152), for the pair that carries it (uniform per pair) ----
     // Depth and colours of the strip are in registers here; the rows above and below it are two more loads each.  One pass
-    // yields the strip's part of sum D and of both edge sums, and the per-pixel edge terms the backward streams; every wave
-    // leaves its own record (no barrier).  SCSFM_SMOOTH_AT (tuning knob): 0 = here, 1 = behind the flush with everything
-    // re-read -- measured on one box, alternating processes (profiles/r06_kernel_experiments.json): loss-path step
-    // 0.4275-0.433 ms here against 0.4315-0.4365 there and 0.441-0.443 with the stand-alone smooth forward.
-#ifndef SCSFM_SMOOTH_AT
-#define SCSFM_SMOOTH_AT 0
-#endif
-#if SCSFM_SMOOTH_AT == 0
+    // yields the strip's part of sum D and of both edge sums, and the per-pixel edge terms the backward streams; the
+    // waves' three sums meet in LDS and leave with the block sum's store further down (one record per tile).  Evaluating
+    // it behind the flush instead (nothing live, everything re-read, a record per wave) measured 0.4315-0.4365 ms per
+    // loss-path step against 0.4275-0.433 here and 0.441-0.443 with the stand-alone smooth forward
+    // (profiles/r06_kernel_experiments.json; the variant: variants/src/patches/r06_smooth_behind_flush.patch).
     if (pa.sm_partials != nullptr) {
       Px<T> row[STRIP], up, dn;
       bool own_row[STRIP];
@@ -196,10 +179,13 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
         up.d = tgt_depth.at(u, vu, ou); up.c0 = ld_plane(tgtP, 0, ou); up.c1 = ld_plane(tgtP, 1, ou); up.c2 = ld_plane(tgtP, 2, ou);
         dn.d = tgt_depth.at(u, vd, od); dn.c0 = ld_plane(tgtP, 0, od); dn.c1 = ld_plane(tgtP, 1, od); dn.c2 = ld_plane(tgtP, 2, od);
       }
-      smooth_tile_part<T, STRIP>(pa, row, up, dn, px, py0, in_x, own_row, sm_icx, sm_icy, H, W, b, plane, strip, col,
-                                 (size_t)(b * nby + blk.y) * nbx + blk.x);
+      T sm[3] = {T(0), T(0), T(0)};
+      smooth_strip<T, STRIP>(row, up, dn, px, py0, in_x, own_row, sm_icx, sm_icy, H, W,
+                             pa.sm_edge ? pa.sm_edge + (size_t)b * plane : nullptr, sm);
+  #pragma unroll
+      for (int i = 0; i < 3; ++i) sm[i] = wave_sum_last(sm[i]);
+      if (col == kWave - 1) { sSm[strip][0] = sm[0]; sSm[strip][1] = sm[1]; sSm[strip][2] = sm[2]; }
     }
-#endif
     // ---- phase 1a ------------------------------------------------------------------------------
     // SCSFM_W_GROUP pixels' gathers are in flight together (tools/march_timing.py: with one pixel after the other this
     // phase took 12,400 of a tile's 48,000 cycles, a third of it vector instructions).  2 since the image loads are
@@ -446,6 +432,12 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     STAMP(4);
     // (contains a barrier: the window's zeroes are visible below even without SSIM)
     block_sum_store<3>(v, red, partials + 3 * ((size_t)(b * nby + blk.y) * nbx + blk.x));
+    if (pa.sm_partials != nullptr && threadIdx.x < 3) {  // (sSm was written in phase 0: several barriers ago)
+      double t = 0;
+#pragma unroll
+      for (int w = 0; w < kThreads / kWave; ++w) t += double(sSm[w][threadIdx.x]);
+      pa.sm_partials[3 * ((size_t)(b * nby + blk.y) * nbx + blk.x) + threadIdx.x] = t;
+    }
     STAMP(5);
     // ---- geometry tail: pass B for the owned pixels, up to the factor the reduction will supply ----
     // (everything downstream of dL/d(warped colour), dL/d diff_depth is linear in them: the dense plane, the
@@ -542,42 +534,6 @@ __device__ __forceinline__ void spec_tile(const BlockId blk, int nbx, int nby, c
     if (!(flags & (SCSFM_DEBUG_X1 | SCSFM_DEBUG_X5)))
       flush_scatter_region<T, Cell, WW, WH>(win, wx0, wy0, cx0, cy0, cx1, cy1, g_scatter, W, ww, kFixed ? T(fix_inv) : T(1));
     STAMP(8);
-#if SCSFM_SMOOTH_AT == 1
-    // (tuning builds: the smooth loss behind everything else -- nothing of the tile is live any more, so the strip and the
-    // rows above and below it are read again)
-    if (pa.sm_partials != nullptr) {
-      // (the row offsets below are the expressions of phase 0: unless the first row is made opaque here, the compiler
-      // keeps phase 0's values alive across the whole tile -- 13 registers spilled)
-      int py0e = py0, pxe = px;
-#if defined(__HIP_DEVICE_COMPILE__)
-      asm volatile("" : "+s"(py0e));
-      asm volatile("" : "+v"(pxe));
-#endif
-      const int u = reflect_index(pxe, W);
-      Px<T> row[STRIP], up, dn;
-      bool own_row[STRIP];
-      auto load = [&](int y) {
-        const int v = t_clampi(y, 0, H - 1);
-        const unsigned off = (unsigned(v) * unsigned(W) + unsigned(u)) * unsigned(sizeof(T));
-        Px<T> q;
-        q.d = tgt_depth.at(u, v, off); q.c0 = ld_plane(tgtP, 0, off); q.c1 = ld_plane(tgtP, 1, off); q.c2 = ld_plane(tgtP, 2, off);
-        return q;
-      };
-      up = load(py0e - 1);
-#pragma unroll
-      for (int k = 0; k < STRIP; ++k) {
-        // (rows of the strip as the warp phase read them: reflected -- only in-image rows are owned or enter an edge)
-        const int v = reflect_index(py0e + k, H);
-        const unsigned off = (unsigned(v) * unsigned(W) + unsigned(u)) * unsigned(sizeof(T));
-        row[k].d = tgt_depth.at(u, v, off); row[k].c0 = ld_plane(tgtP, 0, off); row[k].c1 = ld_plane(tgtP, 1, off); row[k].c2 = ld_plane(tgtP, 2, off);
-        const int ly = strip * STRIP + k;
-        own_row[k] = ly >= 1 && ly <= TH - 2;
-      }
-      dn = load(py0e + STRIP);
-      smooth_tile_part<T, STRIP>(pa, row, up, dn, pxe, py0e, in_x, own_row, sm_icx, sm_icy, H, W, b, plane, strip, col,
-                                 (size_t)(b * nby + blk.y) * nbx + blk.x);
-    }
-#endif
   }
 }
 

@@ -73,6 +73,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert {v["threads"] for v in cb["variants"]} >= {1} and any(v["anomaly_mode"] for v in cb["variants"])
     # pinned, in blocks, with the fastest step beside the median (round 6)
     assert cb["min_ms_per_step"] <= cb["ms_per_step"] and cb["block_medians_ms"] and all(v["omp_proc_bind"] == "close" for v in cb["variants"])
+    assert "configs0_end_to_end" in cb  # (None at this reduced shape: the end-to-end CPU step is run at configs[0]'s size only)
     lib = r["library"]
     assert lib["path"].endswith("scsfm_hip/libscsfm_hip.so") and lib["abi_version"] == 9 and not lib["env_override"]
     # the binary names the sources it was built from, and they are the tree's
