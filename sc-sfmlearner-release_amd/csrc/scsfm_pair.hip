@@ -334,28 +334,44 @@ __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb
     const int nrec = nblk_img;  // one record per tile of an image
     const double cnt_x = (double)B * H * (W - 1), cnt_y = (double)B * (H - 1) * W;
     double loss = 0.0;
-    for (int b = wave; b < B; b += kThreads / kWave) {
-      double v0 = 0, v1 = 0, v2 = 0;
-      // (several records per lane in flight: the 266 records of a 256 x 832 image are ONE L2 round trip per image)
-      constexpr int U8 = 8;
-      for (int i0 = lane; i0 < nrec; i0 += U8 * kWave) {
-        double q[U8][3];
+    // Three images of a wave and five records of each per lane in flight: the 12 x 266 records of a configs[1] launch are
+    // ONE L2 round trip per wave (image after image, eight records at a time, this loop cost the launch 6 us).  The order
+    // of the additions is fixed: records in steps of 64 per lane, the wave butterfly, images in ascending order.
+    constexpr int IM = 3, U5 = 5, NW = kThreads / kWave;
+    for (int b0 = wave; b0 < B; b0 += IM * NW) {
+      double v[IM][3];
 #pragma unroll
-        for (int j = 0; j < U8; ++j) {
-          const int i = i0 + j * kWave;
-          const bool ok = i < nrec;
-          const double* r = pa.sm_partials + 3 * ((size_t)b * nrec + (ok ? i : 0));
-          q[j][0] = r[0]; q[j][1] = r[1]; q[j][2] = r[2];
-          if (!ok) { q[j][0] = 0.0; q[j][1] = 0.0; q[j][2] = 0.0; }
+      for (int m = 0; m < IM; ++m) { v[m][0] = 0.0; v[m][1] = 0.0; v[m][2] = 0.0; }
+      for (int i0 = lane; i0 < nrec; i0 += U5 * kWave) {
+        double q[IM][U5][3];
+#pragma unroll
+        for (int m = 0; m < IM; ++m) {
+          const int bm = b0 + m * NW;
+#pragma unroll
+          for (int j = 0; j < U5; ++j) {
+            const int i = i0 + j * kWave;
+            const bool ok = i < nrec && bm < B;
+            const double* r = pa.sm_partials + 3 * (ok ? (size_t)bm * nrec + i : 0);
+            q[m][j][0] = r[0]; q[m][j][1] = r[1]; q[m][j][2] = r[2];
+            if (!ok) { q[m][j][0] = 0.0; q[m][j][1] = 0.0; q[m][j][2] = 0.0; }
+          }
         }
 #pragma unroll
-        for (int j = 0; j < U8; ++j) { v0 += q[j][0]; v1 += q[j][1]; v2 += q[j][2]; }
+        for (int m = 0; m < IM; ++m)
+#pragma unroll
+          for (int j = 0; j < U5; ++j) { v[m][0] += q[m][j][0]; v[m][1] += q[m][j][1]; v[m][2] += q[m][j][2]; }
       }
-      v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
-      const double den = v0 / ((double)H * W) + 1e-7;  // mean_HW(D) + 1e-7, loss_functions.py:139-140
-      const double L = v1 / cnt_x + v2 / cnt_y;
-      if (lane == 0) { pa.sm_img[2 * b] = den; pa.sm_img[2 * b + 1] = L; }
-      loss += L / den;
+#pragma unroll
+      for (int m = 0; m < IM; ++m) {
+        const int bm = b0 + m * NW;
+        const double v0 = wave_sum(v[m][0]), v1 = wave_sum(v[m][1]), v2 = wave_sum(v[m][2]);
+        if (bm < B) {  // (uniform)
+          const double den = v0 / ((double)H * W) + 1e-7;  // mean_HW(D) + 1e-7, loss_functions.py:139-140
+          const double L = v1 / cnt_x + v2 / cnt_y;
+          if (lane == 0) { pa.sm_img[2 * bm] = den; pa.sm_img[2 * bm + 1] = L; }
+          loss += L / den;
+        }
+      }
     }
     if (lane == 0) sm_red[wave] = loss;
     __syncthreads();
