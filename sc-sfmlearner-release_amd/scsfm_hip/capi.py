@@ -484,9 +484,10 @@ def photo_geometry_fwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
             dist.all_reduce(wrapped_t, op=dist.ReduceOp.MAX, group=group)
         wrapped = int(wrapped_t.item())  # (synchronises: a debugging mode)
         if wrapped:
-            raise WindowOverflow(f"scsfm_hip: {wrapped} fixed-point cell(s) of the scatter window wrapped -- more than 32 "
-                                 "near-cap pixels of one tile land on one reference pixel (an extremely compressive warp); "
-                                 "the depth gradients of this step would be wrong")
+            raise WindowOverflow(f"scsfm_hip: {wrapped} fixed-point cell(s) of the scatter window wrapped although the unit of every "
+                                 "tile's cells follows from an upper bound of what the tile can add to one cell "
+                                 "(csrc/scsfm_geom.h: win_units_of): the bound is violated -- a bug, please report the inputs; "
+                                 "the depth gradients of this step are wrong")
     if group is not None:
         import torch.distributed as dist
         sums = outs[:n, 2:5].contiguous()
@@ -593,7 +594,8 @@ def photo_geometry_bwd(lib, flags, tgt_img, K, ref_imgs, tgt_depths, ref_depths,
             wrapped = int(t.item())
         if wrapped:
             raise WindowOverflow(f"scsfm_hip: fixed-point cells of a scatter window wrapped {wrapped} time(s) in this step's "
-                                 "forward / backward (an extremely compressive warp): depth gradients may be off")
+                                 "forward although their unit is bounded per tile (csrc/scsfm_geom.h: win_units_of): a bug, "
+                                 "please report the inputs; depth gradients may be off")
     g_inputs = None
     if need_imgs is not None or need_K:
         # gradients of the data inputs (scsfm_pairs_bwd_inputs): images accumulate, intrinsics are stored
