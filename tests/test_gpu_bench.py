@@ -65,7 +65,10 @@ def test_single_gpu_line_has_the_contract_fields():
     assert rf["smooth_loss_rides_in_the_kernel"] is True and rf["smooth_edge_plane_bytes_per_launch"] == 4 * 2 * 128 * 416 * 3
     assert abs(rf["kernel_own_frac"] - rf["kernel_own_algorithmic_bytes_per_launch"] / rf["avg_launch_us"] / 1e3 / 8000.0) < 1e-3
     if rf["issue_bound_us"] is not None:  # (quoted for the library the static cost was computed on)
-        assert abs(rf["frac_of_issue_bound"] - rf["issue_bound_us"] / rf["avg_launch_us"]) < 1e-3
+        # (the three values are rounded separately -- 0.1 us, 0.01 us, 1e-4 -- and at this reduced shape the launch is a few
+        #  microseconds long, so the tolerance carries their rounding steps instead of a flat 1e-3)
+        ratio = rf["issue_bound_us"] / rf["avg_launch_us"]
+        assert abs(rf["frac_of_issue_bound"] - ratio) < 1e-3 + ratio * (0.05 / rf["issue_bound_us"] + 0.005 / rf["avg_launch_us"])
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / rf["avg_launch_us"] / 1e3) < 0.01 * rf["achieved"]
     cb = r["cpu_baseline"]
