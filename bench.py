@@ -25,8 +25,10 @@ measured beside it over --loss-steps steps on depth maps / poses resident in HBM
                   here with HIP events on the launching stream, against the 8 TB/s HBM3E peak = `frac` (the judged figure).
                   `bound` names what really bounds it (valu_issue), with `issue_bound_us` / `frac_of_issue_bound` (static
                   issue units x waves per SIMD, profiles/issue_cost_latest.json), `kernel_own_frac`, and `traffic` /
-                  `traffic_detail`: FETCH_SIZE and WRITE_SIZE QUOTED from the committed rocprofv3 --pmc passes of the
-                  loaded library, separately, raw and calibrated against known-bytes kernels
+                  `traffic_detail`: FETCH_SIZE and WRITE_SIZE of rocprofv3 --pmc passes, MEASURED in this run (--pmc-live:
+                  child runs of the loss-path leg under the counters after the timed regions; `traffic_is` says so) or
+                  else QUOTED from the committed passes of the loaded library; separately, raw and calibrated against
+                  known-bytes kernels
   cpu_baseline -- the reference's CPU loss path (the unmodified reference when /root/reference is mounted -- never
                   on the GPU box -- else the oracle, its restatement on the same ATen CPU ops) forward + backward on
                   this host's cores, PINNED, in blocks of >= 15 steps repeated until two consecutive medians agree within
@@ -120,27 +122,95 @@ def pmc_traffic(args, n_pairs, lib_source_id):
         # the training-flags instantiation of the speculative forward (the template list grew over the rounds)
         keys = [n for n in d if n.startswith("scsfm::pair_fwd_spec_kernel<float, true, 7u") and n.endswith(f"|gz{gz}")]
         k = d[keys[0]]
-        out = {"fetch_bytes_raw": int(k["FETCH_SIZE"] * 1024), "write_bytes_raw": int(k["WRITE_SIZE"] * 1024)}
-        cal_path = os.path.join(ROOT, "profiles", "r06_fetch_calibration.json")
-        if os.path.exists(cal_path):
-            cal = json.load(open(cal_path)).get("kernels", {})
-            # measured with known-bytes kernels (tools/ubench/fetch_calib.hip, profiles/r06_fetch_calibration.json): FETCH_SIZE
-            # counts HALF the bytes of coalesced reads (4, 8 and 16 bytes per lane alike) and ALL bytes of 8-byte gathers;
-            # WRITE_SIZE counts all bytes of stores and of float atomics.  The kernel mixes coalesced rows and gathers, so
-            # its true fetch lies between the raw counter (all gathers) and twice it (all coalesced rows)
-            f = {n: v["FETCH_SIZE_over_known"] for n, v in cal.items() if ("read_kernel<unsigned int>" in n or "gather_b64" in n) and "FETCH_SIZE_over_known" in v}
-            w = [v["WRITE_SIZE_over_known"] for n, v in cal.items() if ("write_kernel<unsigned int>" in n or "atomic_f32" in n) and "WRITE_SIZE_over_known" in v]
-            if len(f) == 2 and w:
-                lo, hi = min(f.values()), max(f.values())
-                out["fetch_counter_per_known_byte"] = {"coalesced_b32": [v for n, v in f.items() if "read_kernel" in n][0],
-                                                       "gather_b64": [v for n, v in f.items() if "gather" in n][0]}
-                out["write_counter_per_known_byte"] = round(sum(w) / len(w), 4)
-                out["fetch_bytes_range"] = [int(out["fetch_bytes_raw"] / hi), int(out["fetch_bytes_raw"] / lo)]
-                out["write_bytes"] = int(out["write_bytes_raw"] / (sum(w) / len(w)))
-                out["calibration"] = "profiles/r06_fetch_calibration.json"
+        out = _calibrated({"fetch_bytes_raw": int(k["FETCH_SIZE"] * 1024), "write_bytes_raw": int(k["WRITE_SIZE"] * 1024)})
         return out, "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_round.sh on this library): QUOTED, not measured in this run"
     except (KeyError, ValueError, IndexError, TypeError):
         return None, "profiles/pmc_latest.json has no entry for the dominant kernel"
+
+
+def _calibrated(out):
+    """The two raw counters beside what they mean in bytes (profiles/r06_fetch_calibration.json, known-bytes kernels of
+    tools/ubench/fetch_calib.hip under the same counters): FETCH_SIZE counts HALF the bytes of coalesced reads (4, 8 and 16
+    bytes per lane alike) and ALL bytes of 8-byte gathers; WRITE_SIZE counts all bytes of stores and of float atomics.  The
+    kernel mixes coalesced rows and gathers, so its true fetch lies between the raw counter (all gathers) and twice it (all
+    coalesced rows)."""
+    cal_path = os.path.join(ROOT, "profiles", "r06_fetch_calibration.json")
+    if not os.path.exists(cal_path):
+        return out
+    try:
+        cal = json.load(open(cal_path)).get("kernels", {})
+        f = {n: v["FETCH_SIZE_over_known"] for n, v in cal.items() if ("read_kernel<unsigned int>" in n or "gather_b64" in n) and "FETCH_SIZE_over_known" in v}
+        w = [v["WRITE_SIZE_over_known"] for n, v in cal.items() if ("write_kernel<unsigned int>" in n or "atomic_f32" in n) and "WRITE_SIZE_over_known" in v]
+        if len(f) == 2 and w and min(f.values()) > 0:
+            lo, hi = min(f.values()), max(f.values())
+            out["fetch_counter_per_known_byte"] = {"coalesced_b32": [v for n, v in f.items() if "read_kernel" in n][0],
+                                                   "gather_b64": [v for n, v in f.items() if "gather" in n][0]}
+            out["write_counter_per_known_byte"] = round(sum(w) / len(w), 4)
+            out["fetch_bytes_range"] = [int(out["fetch_bytes_raw"] / hi), int(out["fetch_bytes_raw"] / lo)]
+            out["write_bytes"] = int(out["write_bytes_raw"] / (sum(w) / len(w)))
+            out["calibration"] = "profiles/r06_fetch_calibration.json"
+    except (OSError, ValueError, KeyError, TypeError):
+        pass
+    return out
+
+
+PMC_LIVE_CHILD_ARGS = ["--loss-steps", "3", "--loss-warmup", "1", "--cpu-seconds", "0", "--e2e", "0", "--graph", "0",
+                       "--kernel-iters", "2", "--other-laws", "0", "--pmc-live", "0"]
+
+
+def pmc_traffic_live(args, n_pairs, timeout_s):
+    """-> ({"fetch_bytes_raw", "write_bytes_raw", ...} | None, why).  FETCH_SIZE and WRITE_SIZE per launch of the dominant
+    kernel MEASURED in this run, on this box and this library: two child runs of this file's loss-path leg (eager steps of
+    the reference's call structure on the same synthetic batch) under `rocprofv3 --pmc <counter> --kernel-trace`, ONE
+    counter per pass as MI355X_MICROARCH.md prescribes (no other trace domain beside the counters), after every timed
+    region of the parent has ended.  The average over the dispatches of the training-flags instantiation with this
+    workload's grid is what is reported.  Any failure (no rocprofv3 on PATH, a pass that times out, a database without the
+    kernel) returns None with the reason, and the caller falls back to the committed counters."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3")
+    if tool is None:
+        return None, "no rocprofv3 on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process already runs under a profiler"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                             "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    env["TMPDIR"] = env.get("TMPDIR", "/tmp")
+    shape = ["--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width), "--n-ref", str(args.n_ref),
+             "--dataset", args.dataset, "--depth", args.depth]
+    gz, raw, passes = n_pairs * args.batch, {}, {}
+    with tempfile.TemporaryDirectory(prefix="scsfm_pmc_") as tmp:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [tool, "--pmc", c, "--kernel-trace", "-d", tmp, "-o", f"pmc_{c}", "--", sys.executable,
+                   os.path.abspath(__file__), *PMC_LIVE_CHILD_ARGS, *shape]
+            t0 = time.perf_counter()
+            try:
+                out = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, f"the {c} pass did not finish within {timeout_s:.0f} s"
+            except OSError as exc:
+                return None, f"rocprofv3 could not be started: {exc}"
+            db = os.path.join(tmp, f"pmc_{c}_results.db")
+            if out.returncode != 0 or not os.path.exists(db):
+                return None, f"the {c} pass ended with rc {out.returncode}: {out.stderr[-300:]}"
+            try:
+                row = sqlite3.connect(db).cursor().execute(
+                    "select avg(p.counter_value), count(*), avg(p.duration) from pmc_events p join kernels k on p.dispatch_id = "
+                    "k.dispatch_id where p.counter_name = ? and k.name like '%pair_fwd_spec_kernel<float, true, 7u%' and k.grid_z = ?",
+                    (c, gz)).fetchone()
+            except sqlite3.Error as exc:
+                return None, f"the {c} pass left a database this reader does not understand: {exc}"
+            if not row or not row[1]:
+                return None, f"the {c} pass saw no launch of the dominant kernel"
+            raw[c] = row[0] * 1024.0  # (the counters are in KiB)
+            passes[c] = {"launches": int(row[1]), "avg_launch_us_under_the_counter": round(row[2] / 1e3, 1),
+                         "pass_wall_s": round(time.perf_counter() - t0, 1)}
+    out = _calibrated({"fetch_bytes_raw": int(raw["FETCH_SIZE"]), "write_bytes_raw": int(raw["WRITE_SIZE"])})
+    out["passes"] = passes
+    return out, ("measured in this run: two child runs of this command's loss-path leg (" + " ".join(PMC_LIVE_CHILD_ARGS[:-2]) +
+                 ") under `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace`, one counter per pass, on this box and the loaded library")
 
 
 def issue_bound(lib_source_id, tiles, waves_per_tile=4, simds=1024):
@@ -413,6 +483,11 @@ def main():
     ap.add_argument("--channels-last", type=int, default=0,
                     help="1: the nets of the training-step leg in NHWC memory format (train.py --channels-last); the "
                          "line then says so in config.memory_format and is NOT the headline configuration")
+    ap.add_argument("--pmc-live", type=int, default=1,
+                    help="1: on a 1-GPU run of configs[1] on the headline depth law, MEASURE roofline.traffic in this run (two "
+                         "child runs of the loss-path leg under `rocprofv3 --pmc`, after the timed regions; about a minute), "
+                         "falling back to the committed counters of profiles/pmc_latest.json; 2: at any shape; 0: quote only")
+    ap.add_argument("--pmc-live-timeout", type=float, default=120.0, help="seconds allowed per counter pass")
     ap.add_argument("--exact", type=int, default=0, help="1: exact mask normalisation (scsfm_hip.dist: one all-reduce of "
                                                          "the pairs' raw sums per step) in the distributed legs")
     args = ap.parse_args()
@@ -592,7 +667,21 @@ def main():
     b2b = kt.get("spec_kernel_only_with_smooth", kt["spec_kernel_only"]) if rides else kt["spec_kernel_only"]
     launch_s = in_step_us[0] * 1e-6 if in_step_us[2] > 0 else b2b
     achieved = spec_bytes / launch_s / 1e9
-    traffic, traffic_why = pmc_traffic(args, n_pairs, ident["source_id_in_binary"])
+    traffic, traffic_why, traffic_is = None, None, None
+    headline_shape = (args.batch, args.height, args.width, args.n_ref, args.depth) == (12, 256, 832, 2, "smooth")
+    if rank == 0 and world == 1 and not dist_on and (args.pmc_live >= 2 or (args.pmc_live == 1 and headline_shape)):
+        traffic, traffic_why = pmc_traffic_live(args, n_pairs, args.pmc_live_timeout)
+        if traffic is not None:
+            traffic_is = "measured in this run (rocprofv3 --pmc passes of the loss-path leg, after the timed regions)"
+        else:
+            log(f"[bench] live counters unavailable ({traffic_why}); quoting profiles/pmc_latest.json")
+    live_why = traffic_why
+    if traffic is None:
+        traffic, traffic_why = pmc_traffic(args, n_pairs, ident["source_id_in_binary"])
+        if traffic is not None:
+            traffic_is = "quoted from profiles/ (not measured in this run)"
+        if live_why:
+            traffic_why = f"{traffic_why}; live passes: {live_why}"
     tiles = n_pairs * args.batch * (-(-args.width // 62)) * (-(-args.height // 14))
     ib_us, ib_detail = issue_bound(ident["source_id_in_binary"], tiles)
     own_bytes = int(n_pairs * 40 * n_px + smooth_ride_bytes)
@@ -605,12 +694,13 @@ def main():
         "kernel": f"{DOMINANT_KERNEL} ({n_pairs} pair-directions per launch" + (", carrying the smooth loss of the step's frames)" if rides else ")"),
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
-        # HBM bytes per launch, FETCH_SIZE + WRITE_SIZE (raw counters) of separate `rocprofv3 --pmc` passes of this command:
-        # QUOTED from the committed profiles/pmc_latest.json -- counters cannot be read inside a timed run -- and only when
-        # that file was recorded on the library loaded here; `traffic_detail` has the two counters separately, raw and
-        # calibrated against known-bytes kernels
+        # HBM bytes per launch, FETCH_SIZE + WRITE_SIZE (raw counters) of separate `rocprofv3 --pmc` passes: MEASURED in this
+        # run where that is possible (--pmc-live: child runs of the loss-path leg under the counters, after the timed
+        # regions -- counters cannot be read inside a timed run), else QUOTED from the committed profiles/pmc_latest.json
+        # and only when that file was recorded on the library loaded here; `traffic_is` says which; `traffic_detail` has the
+        # two counters separately, raw and calibrated against known-bytes kernels
         "traffic": None if traffic is None else traffic["fetch_bytes_raw"] + traffic["write_bytes_raw"],
-        "traffic_is": "quoted from profiles/ (not measured in this run)" if traffic is not None else None,
+        "traffic_is": traffic_is,
         "traffic_detail": traffic, "traffic_source": traffic_why,
         "issue_bound_us": None if ib_us is None else round(ib_us, 1),
         "frac_of_issue_bound": None if ib_us is None else round(ib_us / (launch_s * 1e6), 4),

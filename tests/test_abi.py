@@ -127,6 +127,67 @@ def test_bench_quotes_hbm_counters_only_for_the_library_they_were_collected_on(t
     assert bench.pmc_traffic(a, 4, "aaaa")[0] is None
 
 
+def test_bench_measures_hbm_counters_through_child_passes_and_says_so(tmp_path, monkeypatch):
+    """bench.py --pmc-live: roofline.traffic is MEASURED by two child runs of the loss-path leg under `rocprofv3 --pmc`, one
+    counter per pass; every failure (no tool, a pass that fails, a database without the kernel, a profiler already around
+    this process) gives None and the reason, so that the caller quotes the committed counters instead.  The profiler is a
+    stand-in here that writes the database layout pmc_summary.py reads (pmc_events / kernels)."""
+    import argparse
+    import stat
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    for k in [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_"))]:
+        monkeypatch.delenv(k)
+    monkeypatch.setenv("RANK", "0")  # (a launcher's variables must not reach the children)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))  # (no calibration file: raw counters only)
+    a = argparse.Namespace(batch=2, height=128, width=416, n_ref=2, depth="smooth", dataset="kitti")
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    monkeypatch.setenv("PATH", str(bindir))
+    assert bench.pmc_traffic_live(a, 4, 30.0) == (None, "no rocprofv3 on PATH")
+    fake = bindir / "rocprofv3"
+    fake.write_text(textwrap.dedent(f"""\
+        #!{sys.executable}
+        import os, sqlite3, sys
+        a = sys.argv[1:]
+        c, d, o, child = a[a.index("--pmc") + 1], a[a.index("-d") + 1], a[a.index("-o") + 1], a[a.index("--") + 1:]
+        assert "--kernel-trace" in a and len([x for x in a[:a.index("--")] if x.isupper()]) == 1  # one counter, no other domain
+        assert child[1].endswith("bench.py") and child[child.index("--pmc-live") + 1] == "0" and child[child.index("--e2e") + 1] == "0"
+        assert child[child.index("--batch") + 1] == "2" and child[child.index("--width") + 1] == "416" and "RANK" not in os.environ
+        mode = os.environ.get("FAKE_MODE", "ok")
+        if mode == "rc":
+            sys.exit(3)
+        db = sqlite3.connect(os.path.join(d, o + "_results.db"))
+        db.execute("create table kernels(dispatch_id, name, grid_z)")
+        db.execute("create table pmc_events(dispatch_id, counter_name, counter_value, duration)")
+        name = "void scsfm::pair_fwd_spec_kernel<float, true, 7u, false, false>(scsfm::PairBatch<float>)"
+        rows = [(1, name, 8, 100.0), (2, name, 8, 300.0), (3, name, 4, 7000.0), (4, "void scsfm::pairs_combine_kernel<float>()", 8, 9000.0)]
+        for i, n, gz, v in rows:
+            if mode == "absent" and "spec" in n:
+                continue
+            db.execute("insert into kernels values (?,?,?)", (i, n, gz))
+            db.execute("insert into pmc_events values (?,?,?,?)", (i, c, v * (2 if c == "WRITE_SIZE" else 1), 5000.0))
+        db.commit()
+        """))
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    t, why = bench.pmc_traffic_live(a, 4, 30.0)
+    # the average over the dispatches of THIS workload's grid (z = pairs x batch = 8), KiB -> bytes; the other grid and kernel ignored
+    assert t["fetch_bytes_raw"] == 200 * 1024 and t["write_bytes_raw"] == 400 * 1024 and why.startswith("measured in this run")
+    assert t["passes"]["FETCH_SIZE"]["launches"] == 2 and t["passes"]["WRITE_SIZE"]["avg_launch_us_under_the_counter"] == 5.0
+    monkeypatch.setenv("FAKE_MODE", "rc")
+    t, why = bench.pmc_traffic_live(a, 4, 30.0)
+    assert t is None and "rc 3" in why
+    monkeypatch.setenv("FAKE_MODE", "absent")
+    t, why = bench.pmc_traffic_live(a, 4, 30.0)
+    assert t is None and "no launch of the dominant kernel" in why
+    monkeypatch.setenv("FAKE_MODE", "ok")
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    assert bench.pmc_traffic_live(a, 4, 30.0) == (None, "this process already runs under a profiler")
+
+
 def test_product_loader_never_points_at_the_simulator():
     assert _lib.LIB_PATH.endswith(os.path.join("scsfm_hip", "libscsfm_hip.so"))
     src = open(_lib.__file__).read()

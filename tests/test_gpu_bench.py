@@ -84,6 +84,30 @@ def test_single_gpu_line_has_the_contract_fields():
     assert r["collective_backend"] is None and r["rccl_ranks"] == 1
 
 
+def test_hbm_counters_are_measured_in_the_run():
+    """`roofline.traffic` MEASURED by the run itself (round 6, --pmc-live): two child runs of the loss-path leg under
+    `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE`, on this box and the loaded library; here at a reduced shape (--pmc-live 2: the
+    default takes the leg at configs[1] only).  The counters must be of the right size: the kernel writes its dense and
+    scatter planes and the frames' edge planes, and reads every frame at least once (FETCH_SIZE counts between half and all
+    of the bytes: profiles/r06_fetch_calibration.json)."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("no rocprofv3 on this box")
+    env = dict(os.environ, SCSFM_CUDNN_BENCHMARK="0", MIOPEN_FIND_MODE="FAST")
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--cpu-seconds", "0", "--e2e", "0", "--other-laws", "0",
+                "--pmc-live", "2"], env)
+    r = _last_json(out)
+    rf = r["roofline"]
+    assert rf["traffic_is"] is not None and rf["traffic_is"].startswith("measured in this run"), (rf["traffic_source"], out.stderr[-2000:])
+    d = rf["traffic_detail"]
+    n_px = 2 * 128 * 416
+    assert rf["traffic"] == d["fetch_bytes_raw"] + d["write_bytes_raw"] and d["passes"]["FETCH_SIZE"]["launches"] >= 3
+    # writes: 8 B/px dense + scatter planes per pair-direction and the 4 B/px edge planes of 3 frames, plus flush atomics
+    assert 0.9 * (4 * 8 + 3 * 4) * n_px <= d["write_bytes_raw"] <= 3.0 * (4 * 8 + 3 * 4) * n_px
+    # reads: 32 B/px per pair-direction, counted between half and all, some of it served by the caches
+    assert 0.25 * 4 * 32 * n_px <= d["fetch_bytes_raw"] <= 1.5 * 4 * 32 * n_px
+
+
 def test_two_ranks_sharing_the_gpu_report_a_training_rate():
     env = dict(os.environ, SCSFM_BENCH_SHARED_GPU="1", SCSFM_CUDNN_BENCHMARK="0", MIOPEN_FIND_MODE="FAST")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

@@ -22,15 +22,15 @@ timeout 900 python bench.py --steps 10 --warmup 3 --resnet-layers 50 --batch 8 -
 timeout 900 python bench.py --steps 10 --warmup 3 --dataset nyu --height 256 --width 320 --n-ref 4 --batch 16 --loss-steps 30 --loss-warmup 5 --cpu-seconds 0 > $O/bench_${TAG}_cfg4.json 2>> $O/bench_$TAG.err; cut -c1-420 $O/bench_${TAG}_cfg4.json
 cd /tmp
 # (the headline law only -- --other-laws 0 -- and enough eager steps that the dominant kernel has >= 60 launches in the trace)
-echo "=== rocprof kernel trace"; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --loss-steps 60 --loss-warmup 5 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 3 --other-laws 0 > $O/rocprof_$TAG.log 2>&1; echo "rc=$?"
+echo "=== rocprof kernel trace"; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --pmc-live 0 --loss-steps 60 --loss-warmup 5 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 3 --other-laws 0 > $O/rocprof_$TAG.log 2>&1; echo "rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
-  echo "=== rocprof pmc $C"; timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/prof_$TAG -o pmc_$C -- python $R/bench.py --loss-steps 3 --loss-warmup 1 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 2 --other-laws 0 > $O/rocprof_${TAG}_$C.log 2>&1; echo "rc=$?"
+  echo "=== rocprof pmc $C"; timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/prof_$TAG -o pmc_$C -- python $R/bench.py --pmc-live 0 --loss-steps 3 --loss-warmup 1 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 2 --other-laws 0 > $O/rocprof_${TAG}_$C.log 2>&1; echo "rc=$?"
 done
 echo "=== rocprof pmc, iid and scene depth"
 for D in iid scene; do for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/prof_$TAG -o pmc_${D}_$C -- python $R/bench.py --loss-steps 3 --loss-warmup 1 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 2 --other-laws 0 --depth $D > $O/rocprof_${TAG}_${D}_$C.log 2>&1; echo "rc=$?"
+  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/prof_$TAG -o pmc_${D}_$C -- python $R/bench.py --pmc-live 0 --loss-steps 3 --loss-warmup 1 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 2 --other-laws 0 --depth $D > $O/rocprof_${TAG}_${D}_$C.log 2>&1; echo "rc=$?"
 done; done
-echo "=== rocprof kernel trace, scene depth"; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace_scene -- python $R/bench.py --loss-steps 20 --loss-warmup 5 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 3 --other-laws 0 --depth scene > $O/rocprof_${TAG}_scene.log 2>&1; echo "rc=$?"
+echo "=== rocprof kernel trace, scene depth"; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace_scene -- python $R/bench.py --pmc-live 0 --loss-steps 20 --loss-warmup 5 --cpu-seconds 0 --e2e 0 --graph 0 --kernel-iters 3 --other-laws 0 --depth scene > $O/rocprof_${TAG}_scene.log 2>&1; echo "rc=$?"
 cd $R
 # the counters, tied to the library they were collected on (bench.py quotes profiles/pmc_latest.json only for that library)
 SID=$(python -c "import sys; sys.path.insert(0, 'sc-sfmlearner-release_amd'); from scsfm_hip import _lib; print(_lib.get().source_id())" 2>/dev/null | tail -n 1)

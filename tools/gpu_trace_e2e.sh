@@ -4,7 +4,7 @@ TAG=${1:-e2e}
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --steps 5 --warmup 2 --loss-steps 2 --loss-warmup 1 --cpu-seconds 0 --graph 0 --kernel-iters 1 > $O/rocprof_$TAG.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --pmc-live 0 --steps 5 --warmup 2 --loss-steps 2 --loss-warmup 1 --cpu-seconds 0 --graph 0 --kernel-iters 1 > $O/rocprof_$TAG.log 2>&1
 cd $R
 python - $O/prof_$TAG/trace_results.db <<'P' | tee $O/e2e_kernels_$TAG.txt
 import sqlite3, sys, re
