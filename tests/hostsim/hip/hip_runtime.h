@@ -6,11 +6,21 @@
 // never shipped, never loaded by the product (scsfm_hip/_lib.py only ever opens libscsfm_hip.so,
 // which is built by hipcc for gfx950) and proves nothing about performance.
 //
-// Execution model: one OS thread.  Every HIP thread of a workgroup is a ucontext fiber; blocks run
+// Execution model: one OS thread.  Every HIP thread of a workgroup is a fiber; blocks run
 // one after another; __syncthreads() and the wave-level shuffles are cooperative barriers among
 // the fibers of the block / of the 64-lane wave.  Atomics are plain read-modify-writes.
+// Fibers switch through a 20-instruction register swap on x86-64 (glibc's swapcontext makes two
+// rt_sigprocmask system calls per switch, and a kernel of the product switches 10^7 times per launch:
+// the simulated kernels were 70 % of the CPU suite's time); -DHOSTSIM_UCONTEXT, and every other
+// architecture, keeps the portable ucontext fibers.  A fiber parked at a barrier whose generation has
+// not moved is not switched to at all.
 #pragma once
+#if !defined(__x86_64__) && !defined(HOSTSIM_UCONTEXT)
+#define HOSTSIM_UCONTEXT 1
+#endif
+#ifdef HOSTSIM_UCONTEXT
 #include <ucontext.h>
+#endif
 
 #include <cmath>
 #include <cstdint>
@@ -57,9 +67,73 @@ namespace hostsim {
 constexpr int kWave = 64;
 constexpr size_t kStack = 256 * 1024;
 
+#ifdef HOSTSIM_UCONTEXT
+struct Ctx { ucontext_t uc; };
+inline void ctx_switch(Ctx& from, Ctx& to) { swapcontext(&from.uc, &to.uc); }
+inline void ctx_make(Ctx& c, Ctx& back, char* stack, size_t size, void (*fn)()) {
+  getcontext(&c.uc);
+  c.uc.uc_stack.ss_sp = stack;
+  c.uc.uc_stack.ss_size = size;
+  c.uc.uc_link = &back.uc;
+  makecontext(&c.uc, fn, 0);
+}
+#else
+// hostsim_switch(&save_sp, load_sp): push the callee-saved registers and the floating-point control words, park the stack
+// pointer, adopt the other one, pop.  Weak + hidden: every translation unit of the library carries a copy, the linker
+// keeps one.
+extern "C" void hostsim_switch(void** save_sp, void* load_sp) __attribute__((visibility("hidden")));
+asm(R"(
+    .text
+    .weak hostsim_switch
+    .hidden hostsim_switch
+    .type hostsim_switch,@function
+hostsim_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hostsim_switch, .-hostsim_switch
+)");
+struct Ctx { void* sp = nullptr; };
+inline void ctx_switch(Ctx& from, Ctx& to) { hostsim_switch(&from.sp, to.sp); }
+inline void ctx_make(Ctx& c, Ctx&, char* stack, size_t size, void (*fn)()) {
+  // the frame hostsim_switch pops: control words, r15 r14 r13 r12 rbx rbp, return address = fn (entered with the stack
+  // pointer at 8 mod 16, as after a call); fn never returns (the trampoline switches away for good)
+  uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+  uint64_t* f = (uint64_t*)(top - 72);
+  unsigned csr = 0; unsigned short cw = 0;
+  asm volatile("stmxcsr %0" : "=m"(csr));
+  asm volatile("fnstcw %0" : "=m"(cw));
+  f[0] = (uint64_t)csr | ((uint64_t)cw << 32);
+  for (int i = 1; i <= 6; ++i) f[i] = 0;
+  f[7] = (uint64_t)(uintptr_t)fn;  // popped by `ret`: fn starts with the stack pointer at top - 8
+  f[8] = 0;                        // (where a caller's return address would be)
+  c.sp = (void*)f;
+}
+#endif
+
 struct Fiber {
-  ucontext_t ctx;
+  Ctx ctx;
   bool done = false;
+  int wait = 0;           // 0: runnable; 1: parked at the block barrier; 2: at its wave's barrier
+  uint64_t wait_gen = 0;  // ... of this generation
 };
 
 struct State {
@@ -67,7 +141,7 @@ struct State {
   int nthreads = 0, cur = 0, live = 0;
   std::vector<Fiber> fibers;
   std::vector<char> stacks;
-  ucontext_t main_ctx;
+  Ctx main_ctx;
   const std::function<void()>* body = nullptr;
   // block barrier
   int arrived = 0;
@@ -95,26 +169,33 @@ inline void set_thread(int t) {
 inline void yield() {
   State& s = S();
   int me = s.cur;
-  swapcontext(&s.fibers[me].ctx, &s.main_ctx);
+  ctx_switch(s.fibers[me].ctx, s.main_ctx);
 }
 inline void trampoline() {
   State& s = S();
   (*s.body)();
   s.fibers[s.cur].done = true;
-  swapcontext(&s.fibers[s.cur].ctx, &s.main_ctx);
+  ctx_switch(s.fibers[s.cur].ctx, s.main_ctx);
+  abort();  // (a finished fiber is never resumed)
 }
 inline void block_barrier() {
   State& s = S();
   uint64_t g = s.gen;
   if (++s.arrived >= s.live) { s.arrived = 0; s.gen++; return; }
+  Fiber& f = s.fibers[s.cur];
+  f.wait = 1; f.wait_gen = g;
   while (s.gen == g) yield();
+  f.wait = 0;
 }
 inline void wave_barrier() {
   State& s = S();
   int w = s.cur / kWave;
   uint64_t g = s.w_gen[w];
   if (++s.w_arrived[w] >= s.w_live[w]) { s.w_arrived[w] = 0; s.w_gen[w]++; return; }
+  Fiber& f = s.fibers[s.cur];
+  f.wait = 2; f.wait_gen = g;
   while (s.w_gen[w] == g) yield();
+  f.wait = 0;
 }
 template <class T>
 inline T shfl(T v, int src_lane) {
@@ -143,12 +224,8 @@ inline void run_block(const std::function<void()>& body) {
   s.xbuf.assign((size_t)nw * kWave, 0);
   for (int t = 0; t < n; ++t) {
     Fiber& f = s.fibers[t];
-    f.done = false;
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = s.stacks.data() + (size_t)t * kStack;
-    f.ctx.uc_stack.ss_size = kStack;
-    f.ctx.uc_link = &s.main_ctx;
-    makecontext(&f.ctx, (void (*)())trampoline, 0);
+    f.done = false; f.wait = 0;
+    ctx_make(f.ctx, s.main_ctx, s.stacks.data() + (size_t)t * kStack, kStack, (void (*)())trampoline);
   }
   int remaining = n;
   long spins = 0;
@@ -163,8 +240,10 @@ inline void run_block(const std::function<void()>& body) {
       const int t = reverse ? n - 1 - k : k;
       Fiber& f = s.fibers[t];
       if (f.done) continue;
+      // parked at a barrier that has not opened: nothing to run (it would look at the generation and yield again)
+      if (f.wait == 1 ? s.gen == f.wait_gen : (f.wait == 2 && s.w_gen[t / kWave] == f.wait_gen)) continue;
       set_thread(t);
-      swapcontext(&s.main_ctx, &f.ctx);
+      ctx_switch(s.main_ctx, f.ctx);
       if (f.done) {
         --remaining; ++progressed;
         // a finished thread no longer takes part in barriers (hardware counts live waves only)
