@@ -1,0 +1,114 @@
+"""Seeded sweep of the pair-loss entry points over shapes nobody chose: image sizes that are no multiple of a tile, a
+wave or a strip in either direction (down to images lower than a strip and narrower than a wave), 1-3 references, every
+flag combination of compute_pairwise_loss (loss_functions.py:95-119), both paddings (inverse_warp.py:262,267), and the
+three states of the speculation (hint right / hint wrong -> the backward's own passes / no hint -> plain forward), fp64
+instantiations against the fp64 oracle.  The same cases run on the kernel simulator (CPU CI) and on the hardware.
+
+The cases are drawn once from a fixed seed, so a failure names a reproducible case; the batch is sized so that the
+10000-pixel gates of mean_on_mask (loss_functions.py:125) are open in most cases and closed in a few (both must hold)."""
+import random
+
+import pytest
+import torch
+
+from oracle import scsfm_oracle as O
+from scsfm_hip import capi, synth
+
+
+def _cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        H = rng.choice([3, 5, 9, 14, 15, 17, 29, 31, 33, 47, 61])
+        W = rng.choice([5, 33, 61, 62, 63, 64, 65, 67, 125, 127, 129, 190])
+        # most cases above the gate (B*H*W > 10000 and a fair share of valid pixels), every fourth below it
+        want = 3000 if i % 4 == 3 else 26000
+        B = max(1, min(48, -(-want // (H * W))))
+        n_ref = rng.choice([1, 1, 2, 3])
+        flags3 = (rng.randint(0, 1), rng.randint(0, 1), rng.randint(0, 1))
+        pad = rng.choice(["zeros", "zeros", "border"])
+        state = rng.choice(["holds", "wrong", "plain"])
+        up = (rng.choice([1.0, 0.7, 0.25]), rng.choice([0.5, 1.3, 0.0]))
+        out.append((H, W, B, n_ref, flags3, pad, state, up, 1000 + i))
+    return out
+
+
+CASES = _cases(20, seed=20260930)
+IDS = [f"{H}x{W}x{B}-r{n}-f{''.join(map(str, f))}-{pad}-{state}" for H, W, B, n, f, pad, state, up, seed in CASES]
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double().reshape(-1), b.detach().cpu().double().reshape(-1)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-300)) if float(b.abs().max()) > 0 else float(a.abs().max())
+
+
+def _run_case(lib, case, device):
+    H, W, B, n_ref, flags3, pad, state, up, seed = case
+    d = synth.make_batch(B, H, W, n_ref=n_ref, seed=seed, depth="smooth")
+    c = lambda x: x.double().contiguous()
+    ti, K = c(d["tgt_img"]), c(d["intrinsics"])
+    ris = [c(r) for r in d["ref_imgs"]]
+    tds, rds = [c(d["tgt_depth"][0])], [[c(r[0])] for r in d["ref_depths"]]
+    ps, pis = [c(p) for p in d["poses"]], [c(p) for p in d["poses_inv"]]
+    lf = lambda x: x.clone().requires_grad_(True)
+    td, rd = [lf(t) for t in tds], [[lf(t) for t in r] for r in rds]
+    pp, pi = [lf(p) for p in ps], [lf(p) for p in pis]
+    po, go = O.photo_and_geometry_loss(ti, ris, K, td, rd, pp, pi, 1, *flags3, pad)
+    tot = up[0] * po + up[1] * go
+    if tot.requires_grad:
+        tot.backward()
+    hint = {"holds": up, "wrong": (up[0] * 0.5 + 0.1, up[1] + 0.3), "plain": None}[state]
+    g = lambda x: x.to(device)
+    fl = capi.make_flags(*flags3, pad)
+    a = dict(ti=g(ti), K=g(K), ris=[g(r) for r in ris], tds=[g(t) for t in tds], rds=[[g(t) for t in r] for r in rds],
+             ps=[g(p) for p in ps], pis=[g(p) for p in pis])
+    photo, geom, _, ws = capi.photo_geometry_fwd(lib, fl, a["ti"], a["K"], a["ris"], a["tds"], a["rds"], a["ps"], a["pis"], hint=hint)
+    po, go = po.detach(), go.detach()
+    assert abs(float(photo) - float(po)) < 1e-11 * max(1.0, abs(float(po))), (float(photo), float(po))
+    assert abs(float(geom) - float(go)) < 1e-11 * max(1.0, abs(float(go))), (float(geom), float(go))
+    t = lambda v: torch.tensor([v], dtype=torch.float64, device=device)
+    g_td, g_rd, g_p, g_pi = capi.photo_geometry_bwd(lib, fl, a["ti"], a["K"], a["ris"], a["tds"], a["rds"], a["ps"], a["pis"], ws,
+                                                    t(up[0]), t(up[1]))
+    z = lambda x: x.grad if x.grad is not None else torch.zeros_like(x)
+    assert _rel(g_td[0], z(td[0])) < 1e-9
+    for i in range(n_ref):
+        assert _rel(g_rd[i][0], z(rd[i][0])) < 1e-9, i
+        assert _rel(g_p[i], z(pp[i])) < 1e-9 and _rel(g_pi[i], z(pi[i])) < 1e-9, i
+    return float(po), float(go)
+
+
+def test_the_sweep_covers_what_it_says():
+    """The drawn cases contain every state of the speculation, both paddings, 1-3 references, images lower than a strip
+    (H < 4) or a tile's interior (H < 14) and narrower / wider than a wave, and both settings of every flag."""
+    states = {c[6] for c in CASES}
+    assert states == {"holds", "wrong", "plain"} and {c[5] for c in CASES} == {"zeros", "border"}
+    assert {c[3] for c in CASES} >= {1, 2} and any(c[0] < 14 for c in CASES) and any(c[1] < 64 for c in CASES) and any(c[1] > 64 for c in CASES)
+    for k in range(3):
+        assert {c[4][k] for c in CASES} == {0, 1}
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_seeded_shapes_on_the_simulator(case):
+    from hostsim import harness
+    _run_case(harness.lib(), case, torch.device("cpu"))
+
+
+def test_some_gate_is_open_and_some_closed_in_the_sweep():
+    """(what the two batch sizes of the draw are for: the sweep must see open gates -- positive losses -- AND closed ones)"""
+    from hostsim import harness
+    lib = harness.lib()
+    open_case = next(c for i, c in enumerate(CASES) if i % 4 != 3 and c[4][1] == 0)   # no weight mask, big batch
+    closed_case = next(c for i, c in enumerate(CASES) if i % 4 == 3)
+    po, _ = _run_case(lib, open_case, torch.device("cpu"))
+    pc, gc = _run_case(lib, closed_case, torch.device("cpu"))
+    assert po > 0 and pc == 0.0 and gc == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_seeded_shapes_on_the_hardware(case):
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from scsfm_hip import _lib
+    lib = _lib.get()
+    assert lib.path.endswith("libscsfm_hip.so")  # the hipcc build, not the simulator
+    _run_case(lib, case, torch.device("cuda:0"))
