@@ -112,3 +112,80 @@ def test_seeded_shapes_on_the_hardware(case):
     lib = _lib.get()
     assert lib.path.endswith("libscsfm_hip.so")  # the hipcc build, not the simulator
     _run_case(lib, case, torch.device("cuda:0"))
+
+
+# ---- the other public callables of the path at seeded odd shapes: compute_smooth_loss (loss_functions.py:132-159), inverse_warp2
+# (inverse_warp.py:230-269) and the SSIM module (loss_functions.py:11-42), values and gradients, fp64, through the host mirror
+def _aux_cases(n, seed):
+    rng = random.Random(seed)
+    return [(rng.choice([2, 3, 5, 9, 16, 17, 31, 47]), rng.choice([2, 5, 33, 63, 64, 65, 129, 190]), rng.choice([1, 2, 3]),
+             rng.choice(["zeros", "border"]), 2000 + i) for i in range(n)]
+
+
+AUX_CASES = _aux_cases(8, seed=930)
+AUX_IDS = [f"{H}x{W}x{B}-{pad}" for H, W, B, pad, seed in AUX_CASES]
+
+
+def _run_aux_case(LF, IW, case, device):
+    H, W, B, pad, seed = case
+    d = synth.make_batch(B, H, W, n_ref=2, seed=seed, depth="smooth")
+    c = lambda x: x.double().contiguous()
+    lf = lambda x: c(x).clone().requires_grad_(True)
+    dv = lambda x: c(x).to(device).clone().requires_grad_(True)
+    gen = torch.Generator().manual_seed(seed)
+    # compute_smooth_loss over the three frames
+    td, rds = [lf(d["tgt_depth"][0])], [[lf(r[0])] for r in d["ref_depths"]]
+    so = O.smooth_loss(td, c(d["tgt_img"]), rds, [c(r) for r in d["ref_imgs"]])
+    so.backward()
+    tdv, rdv = [dv(d["tgt_depth"][0])], [[dv(r[0])] for r in d["ref_depths"]]
+    sh = LF.compute_smooth_loss(tdv, c(d["tgt_img"]).to(device), rdv, [c(r).to(device) for r in d["ref_imgs"]])
+    sh.backward()
+    assert abs(float(sh.detach()) - float(so.detach())) < 1e-11 * max(1.0, abs(float(so.detach())))
+    assert _rel(tdv[0].grad, td[0].grad) < 1e-9 and all(_rel(a[0].grad, b[0].grad) < 1e-9 for a, b in zip(rdv, rds))
+    # inverse_warp2: four maps and the gradients of a random functional of them
+    img, dep, rdep, pose, K = c(d["ref_imgs"][0]), lf(d["tgt_depth"][0]), lf(d["ref_depths"][0][0]), lf(d["poses"][0]), c(d["intrinsics"])
+    wts = [torch.rand(B, 3, H, W, generator=gen, dtype=torch.float64), torch.rand(B, 1, H, W, generator=gen, dtype=torch.float64),
+           torch.rand(B, 1, H, W, generator=gen, dtype=torch.float64)]
+    o = O.inverse_warp2(img, dep, rdep, pose, K, pad)
+    (o[0] * wts[0]).sum().add((o[2] * wts[1]).sum()).add((o[3] * wts[2]).sum()).backward()
+    depv, rdepv, posev = dv(d["tgt_depth"][0]), dv(d["ref_depths"][0][0]), dv(d["poses"][0])
+    h = IW.inverse_warp2(img.to(device), depv, rdepv, posev, K.to(device), pad)
+    (h[0] * wts[0].to(device)).sum().add((h[2] * wts[1].to(device)).sum()).add((h[3] * wts[2].to(device)).sum()).backward()
+    for a, b in zip(h, o):
+        assert a.shape == b.shape and float((a.detach().cpu().double() - b.detach().double()).abs().max()) < 1e-9
+    assert _rel(depv.grad, dep.grad) < 1e-9 and _rel(rdepv.grad, rdep.grad) < 1e-9 and _rel(posev.grad, pose.grad) < 1e-9
+    # SSIM module (needs a 3x3 window's reflection: H, W >= 2)
+    x = torch.rand(B, 3, H, W, generator=gen, dtype=torch.float64)
+    y = (x + 0.3 * torch.rand(B, 3, H, W, generator=gen, dtype=torch.float64)).contiguous()
+    w = torch.rand(B, 3, H, W, generator=gen, dtype=torch.float64)
+    xc, yc = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    oc = O.ssim_map(xc, yc)
+    (oc * w).sum().backward()
+    xd, yd = x.to(device).requires_grad_(True), y.to(device).requires_grad_(True)
+    od = LF.compute_ssim_loss(xd, yd)
+    (od * w.to(device)).sum().backward()
+    assert float((od.detach().cpu() - oc.detach()).abs().max()) < 1e-10
+    assert _rel(xd.grad, xc.grad) < 1e-9 and _rel(yd.grad, yc.grad) < 1e-9
+
+
+@pytest.mark.parametrize("case", AUX_CASES, ids=AUX_IDS)
+def test_seeded_shapes_of_the_other_callables_on_the_simulator(case, monkeypatch):
+    import inverse_warp as IW
+    import loss_functions as LF
+    from hostsim import harness
+    from scsfm_hip import _lib, ops
+    lib = harness.lib()
+    monkeypatch.setattr(_lib, "get", lambda: lib)
+    monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)
+    _run_aux_case(LF, IW, case, torch.device("cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", AUX_CASES, ids=AUX_IDS)
+def test_seeded_shapes_of_the_other_callables_on_the_hardware(case):
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import inverse_warp as IW
+    import loss_functions as LF
+    from scsfm_hip import _lib
+    assert _lib.get().path.endswith("libscsfm_hip.so")
+    _run_aux_case(LF, IW, case, torch.device("cuda:0"))
