@@ -299,34 +299,40 @@ struct StepTotal {
   T* out;
   T w1, w2, w3;
 };
+// Grid: one workgroup per pair-direction for the pair losses and -- when a pair of the launch carries its target frame's
+// smooth loss -- a second row of workgroups (blockIdx.x >= npairs) for the frames' records, so that the two chains of L2
+// round trips run side by side instead of one behind the other (12-14 us -> what the longer of the two takes); whichever
+// workgroup of either role arrives last adds up the call's totals.
 template <typename T>
-__global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb, int nblocks, int nblk_img, double spec,
+__global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb, int npairs, int nblocks, int nblk_img, double spec,
                                                                  double w_photo, double w_geom, T* total, int first,
                                                                  const double* __restrict__ hint, StepTotal<T> st, int H, int W) {
   __shared__ double red[3 * (kThreads / kWave)];
-  const PairArgs<T>& pa = pb.p[blockIdx.x];
+  const bool smooth_role = (int)blockIdx.x >= npairs;  // (uniform per workgroup)
+  const PairArgs<T>& pa = pb.p[smooth_role ? blockIdx.x - npairs : blockIdx.x];
   const double* __restrict__ partials = pa.partials;
   double* __restrict__ sums = pa.sums;
   T* __restrict__ out = pa.out;
   double v[3] = {0, 0, 0};
-  // four records per thread in flight (the loop is a chain of L2 round trips: 13 of them for the 3192 records of a
-  // configs[1] launch with one record per iteration, 4 this way); same order of additions per thread on every run
-  constexpr int U = 4;
-  for (int i0 = threadIdx.x; i0 < nblocks; i0 += U * kThreads) {
-    double q[U][3];
+  if (!smooth_role) {
+    // four records per thread in flight (the loop is a chain of L2 round trips: 13 of them for the 3192 records of a
+    // configs[1] launch with one record per iteration, 4 this way); same order of additions per thread on every run
+    constexpr int U = 4;
+    for (int i0 = threadIdx.x; i0 < nblocks; i0 += U * kThreads) {
+      double q[U][3];
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const int i = i0 + j * kThreads;
-      const bool ok = i < nblocks;
-      const double* r = partials + 3 * (ok ? i : 0);
-      q[j][0] = r[0]; q[j][1] = r[1]; q[j][2] = r[2];
-      if (!ok) { q[j][0] = 0.0; q[j][1] = 0.0; q[j][2] = 0.0; }
+      for (int j = 0; j < U; ++j) {
+        const int i = i0 + j * kThreads;
+        const bool ok = i < nblocks;
+        const double* r = partials + 3 * (ok ? i : 0);
+        q[j][0] = r[0]; q[j][1] = r[1]; q[j][2] = r[2];
+        if (!ok) { q[j][0] = 0.0; q[j][1] = 0.0; q[j][2] = 0.0; }
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) { v[0] += q[j][0]; v[1] += q[j][1]; v[2] += q[j][2]; }
     }
-#pragma unroll
-    for (int j = 0; j < U; ++j) { v[0] += q[j][0]; v[1] += q[j][1]; v[2] += q[j][2]; }
-  }
-  block_sum<3>(v, red);
-  if (pa.sm_partials != nullptr) {
+    block_sum<3>(v, red);
+  } else if (pa.sm_partials != nullptr) {
     // the target frame's smooth loss from the tiles' {sum D, Sx, Sy} records (smooth_finalize_kernel's arithmetic: each
     // wave reduces whole images with shuffles, in a fixed order, then the waves' contributions meet in LDS)
     __shared__ double sm_red[kThreads / kWave];
@@ -382,20 +388,22 @@ __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb
     }
   }
   if (threadIdx.x == 0) {
-    publish_losses(v[0], v[1], v[2], sums, out);
-    out[7] = T(*window_overflow_counter(pa));  // (0 unless the forward was launched with SCSFM_DEBUG_CHECK_WINDOW and a cell wrapped)
-    if (hint && spec != 0.0) {  // the weights the speculative forward read from the device (scsfm_pair_desc::hint)
-      w_photo = hint[0]; w_geom = hint[1];
-      if (w_photo == 0.0) spec = 0.0;  // nothing to factor out: the backward runs its own passes
+    if (!smooth_role) {
+      publish_losses(v[0], v[1], v[2], sums, out);
+      out[7] = T(*window_overflow_counter(pa));  // (0 unless the forward was launched with SCSFM_DEBUG_CHECK_WINDOW and a cell wrapped)
+      if (hint && spec != 0.0) {  // the weights the speculative forward read from the device (scsfm_pair_desc::hint)
+        w_photo = hint[0]; w_geom = hint[1];
+        if (w_photo == 0.0) spec = 0.0;  // nothing to factor out: the backward runs its own passes
+      }
+      sums[8] = spec; sums[9] = w_photo; sums[10] = w_geom;
+      sums[11] = double(nblk_img);  // partial records per image the forward left (the pose reduction of the backward reads them)
     }
-    sums[8] = spec; sums[9] = w_photo; sums[10] = w_geom;
-    sums[11] = double(nblk_img);  // partial records per image the forward left (the pose reduction of the backward reads them)
     if (total) {
       __threadfence();
       if (atomicAdd(finalize_counter(pb), 1u) == gridDim.x - 1) {
         __threadfence();
         T photo = T(0), geom = T(0);
-        for (unsigned i = 0; i < gridDim.x; ++i) {
+        for (int i = 0; i < npairs; ++i) {
           const volatile T* o = pb.p[i].out;
           photo += o[0]; geom += o[1];
         }
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void pair_finalize_kernel(PairBatch<T> pb
         total[1] = first ? geom : total[1] + geom;
         if (st.smooth_total) {  // the frames' smooth losses, in descriptor order
           T smooth = T(0);
-          for (unsigned i = 0; i < gridDim.x; ++i)
+          for (int i = 0; i < npairs; ++i)
             if (pb.p[i].sm_partials && pb.p[i].sm_out) smooth += *const_cast<const volatile T*>(pb.p[i].sm_out);
           st.smooth_total[0] = first ? smooth : st.smooth_total[0] + smooth;
           if (st.out) {
@@ -1339,8 +1347,10 @@ static int pairs_fwd_chunk(int n, const scsfm_pair_desc* d, int B, int H, int W,
       else hipLaunchKernelGGL((pair_fwd_kernel<T, false, true>), grid, dim3(kThreads), 0, stream, pb, B, H, W, flags);
     }
   }
+  bool any_smooth = false;
+  for (int i = 0; i < n; ++i) any_smooth = any_smooth || pb.p[i].sm_partials != nullptr;
   if (!kernel_only)
-    hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(n), dim3(kThreads), 0, stream, pb, (int)(grid.x * grid.y * B),
+    hipLaunchKernelGGL((pair_finalize_kernel<T>), dim3(any_smooth ? 2 * n : n), dim3(kThreads), 0, stream, pb, n, (int)(grid.x * grid.y * B),
                        (int)(grid.x * grid.y), spec ? 1.0 : 0.0, spec ? w_photo : 0.0, spec ? w_geom : 0.0, total, first ? 1 : 0,
                        spec ? hint : nullptr, st, H, W);
   return launch_status();
