@@ -41,7 +41,11 @@ ENTRYWISE_MAX_FACTOR = {"smooth": 4.0, "iid": 4.0, "scene": 4.0}
 # arithmetic's own worst entry on the three maps, and 81 .. 90 % of the iid entries are judged (91 .. 96 % elsewhere).
 # Round 6: FROZEN (tests/test_oracle_golden.py::test_the_gate_margins_of_the_gradient_judgement_are_frozen holds the margins
 # and these constants); the iid share raised from 0.78 to what round 5 measured (0.81 .. 0.90) minus two points.
-ENTRYWISE_MIN_SHARE = {"smooth": 0.90, "iid": 0.79, "scene": 0.90}
+# End of round 6: the slope-aware margin NARROWED from the constant 5e-4 px to two ulp of the largest coordinate (1.2e-4 px at
+# W = 832; oracle.slope_margin_px) -- tools/diag_margins.py on the hardware: every worst-entry ratio below is the same at
+# 5e-4, 2.5e-4, 1.2e-4 and 6e-5 px, only a zero margin lets the flipped gates in (profiles/r06_margin_sensitivity.json) --
+# so more entries are judged under the same bounds: measured shares 0.931 .. 0.969 (iid 0.917 / 0.957 / 0.957), minus two points
+ENTRYWISE_MIN_SHARE = {"smooth": 0.91, "iid": 0.89, "scene": 0.91}
 # error quantiles (median, 99 %, 99.9 %, 99.99 %) of the judged entries: HIP against the reference's fp32 arithmetic
 ENTRYWISE_QUANTILE_FACTORS = (2.0, 2.0, 2.0, 2.5)
 # test_iid_pose_gradients_as_row_statistics_over_seeds: HIP's row errors against the fp32 reference arithmetic's
@@ -807,7 +811,7 @@ def test_depth_gradients_entrywise_away_from_the_gates(LF, dev, B, depth, pad):
     fixed-point scatter window) -- judged entry by entry at BASELINE size, with NO outlier allowance.
 
     Every entry of the three depth gradients of compute_photo_and_geometry_loss whose value cannot hinge on a gate
-    decided within fp32 round-off (oracle.pairwise_gate_margins, evaluated in fp64; >= 90 % of the entries, 78 % on iid inputs) must lie
+    decided within fp32 round-off (oracle.pairwise_gate_margins, evaluated in fp64; >= 91 % of the entries, 89 % on iid inputs) must lie
     within ENTRYWISE_MAX_FACTOR[depth] x the worst such entry of the reference's own fp32 arithmetic in the same run -- the entries set aside
     are off by up to a third of it, in the reference's own fp32 arithmetic as much as here (measured,
     tools/diag_gates.py) -- and the error distribution over those entries (median, 99 %, 99.9 %) must be no wider than
