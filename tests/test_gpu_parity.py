@@ -44,8 +44,9 @@ ENTRYWISE_MAX_FACTOR = {"smooth": 4.0, "iid": 4.0, "scene": 4.0}
 # End of round 6: the slope-aware margin NARROWED from the constant 5e-4 px to two ulp of the largest coordinate (1.2e-4 px at
 # W = 832; oracle.slope_margin_px) -- tools/diag_margins.py on the hardware: every worst-entry ratio below is the same at
 # 5e-4, 2.5e-4, 1.2e-4 and 6e-5 px, only a zero margin lets the flipped gates in (profiles/r06_margin_sensitivity.json) --
-# so more entries are judged under the same bounds: measured shares 0.931 .. 0.969 (iid 0.917 / 0.957 / 0.957), minus two points
-ENTRYWISE_MIN_SHARE = {"smooth": 0.91, "iid": 0.89, "scene": 0.91}
+# and the constant value margin eps_val halved to 1e-4 on the same evidence (identical ratios down to 5e-5), so more entries are
+# judged under the same bounds: measured shares 0.953 .. 0.980 (iid 0.931 / 0.964 / 0.964), minus two points
+ENTRYWISE_MIN_SHARE = {"smooth": 0.93, "iid": 0.91, "scene": 0.93}
 # error quantiles (median, 99 %, 99.9 %, 99.99 %) of the judged entries: HIP against the reference's fp32 arithmetic
 ENTRYWISE_QUANTILE_FACTORS = (2.0, 2.0, 2.0, 2.5)
 # test_iid_pose_gradients_as_row_statistics_over_seeds: HIP's row errors against the fp32 reference arithmetic's
@@ -811,7 +812,7 @@ def test_depth_gradients_entrywise_away_from_the_gates(LF, dev, B, depth, pad):
     fixed-point scatter window) -- judged entry by entry at BASELINE size, with NO outlier allowance.
 
     Every entry of the three depth gradients of compute_photo_and_geometry_loss whose value cannot hinge on a gate
-    decided within fp32 round-off (oracle.pairwise_gate_margins, evaluated in fp64; >= 91 % of the entries, 89 % on iid inputs) must lie
+    decided within fp32 round-off (oracle.pairwise_gate_margins, evaluated in fp64; >= 93 % of the entries, 91 % on iid inputs) must lie
     within ENTRYWISE_MAX_FACTOR[depth] x the worst such entry of the reference's own fp32 arithmetic in the same run -- the entries set aside
     are off by up to a third of it, in the reference's own fp32 arithmetic as much as here (measured,
     tools/diag_gates.py) -- and the error distribution over those entries (median, 99 %, 99.9 %) must be no wider than

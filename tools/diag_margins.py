@@ -2,7 +2,7 @@
 """How the entry-wise gradient judgement (tests/test_gpu_parity.py::test_depth_gradients_entrywise_away_from_the_gates)
 moves with the slope-aware margin `eps_slope_px` of oracle.pairwise_gate_margins: for each of the test's four cases and
 each of a list of margins, the judged share and HIP-worst / reference-fp32-worst of every depth-gradient map, plus the
-quantile ratios.  One GPU run per case (the gradients do not depend on the margin); the margins are evaluated on the host
+quantile ratios.  A margin argument of the form slope:px:val varies eps_px and eps_val as well.  One GPU run per case (the gradients do not depend on the margin); the margins are evaluated on the host
 in fp64.  Prints one JSON line per (case, margin).  Run on the GPU box:  python tools/diag_margins.py 5e-4 2.5e-4 1.2e-4 0"""
 import json
 import os
@@ -18,7 +18,7 @@ from oracle import scsfm_oracle as O  # noqa: E402
 from scsfm_hip import synth  # noqa: E402
 
 
-def unsafe_maps(d, n_ref, pad, eps_slope_px):
+def unsafe_maps(d, n_ref, pad, eps_slope_px, eps_px=2e-3, eps_val=2e-4):
     c = lambda t: t.double()
     ti, K = c(d["tgt_img"]), c(d["intrinsics"])
     unsafe = [torch.zeros(ti.shape[0], ti.shape[2], ti.shape[3], dtype=torch.bool) for _ in range(1 + n_ref)]
@@ -26,7 +26,7 @@ def unsafe_maps(d, n_ref, pad, eps_slope_px):
         ri, td, rd = c(d["ref_imgs"][i]), c(d["tgt_depth"][0]), c(d["ref_depths"][i][0])
         for (a_img, b_img, a_d, b_d, pose, ia, ib) in ((ti, ri, td, rd, c(d["poses"][i]), 0, 1 + i),
                                                        (ri, ti, rd, td, c(d["poses_inv"][i]), 1 + i, 0)):
-            m = O.pairwise_gate_margins(a_img, b_img, a_d, b_d, pose, K, 1, 1, 1, pad, eps_slope_px=eps_slope_px)
+            m = O.pairwise_gate_margins(a_img, b_img, a_d, b_d, pose, K, 1, 1, 1, pad, eps_px=eps_px, eps_val=eps_val, eps_slope_px=eps_slope_px)
             dense, scatter = O.unsafe_gradient_entries(m)
             unsafe[ia] |= dense
             unsafe[ib] |= scatter
@@ -53,7 +53,9 @@ def main(margins):
         g32 = run("cpu", O.photo_and_geometry_loss, torch.float32)
         g64 = run("cpu", O.photo_and_geometry_loss, torch.float64)
         for eps in margins:
-            unsafe = unsafe_maps(d, n_ref, pad, eps)
+            # a margin is either the slope margin alone, or "slope:px:val" (the other two margins as well)
+            trip = [float(x) for x in str(eps).split(":")]
+            unsafe = unsafe_maps(d, n_ref, pad, *trip)
             maps = []
             for a, o, c, u in zip(gh, g32, g64, unsafe):
                 a, o, c = a[:, 0], o[:, 0], c[:, 0]
@@ -69,4 +71,4 @@ def main(margins):
 
 
 if __name__ == "__main__":
-    main([float(x) for x in sys.argv[1:]] or [5e-4, 2.5e-4, 1.2e-4, 0.0])
+    main(sys.argv[1:] or ["5e-4", "2.5e-4", "1.2e-4", "0"])
