@@ -31,6 +31,13 @@ POSE_RTOL_IID = 3e-2
 # statistic (which near-gate entry the margins just fail to set aside) -- measured in round 4 (gpurun_out/pytest_gpu_r04d.log
 # and the session after it): 0.8 .. 1.5x on image-like depth, 2.9x with border padding, 3.6 .. 6.6x on iid depth (5.8e-2
 # against 8.8e-3 of the scale).  Round 3 held these to the constants 3e-3 / 1e-1; the bounds are now relative to the run.
+# test_hot_path_against_oracle: share of a depth gradient's entries where HIP fp32 and the ORACLE's fp32 may differ by more than
+# 0.5 % of the map's scale (pixels whose gate the two fp32 evaluations decided differently); x6 for a coarser scale's map (one
+# of its entries pools up to 64 pixels' flips).  Rounds 1-5 allowed 2e-3 (x4: 8e-3) without ever recording what is measured;
+# end of round 6 the test reports it (suite summary; profiles/r06_pytest_gpu.txt): 2.8e-5 .. 5.3e-5 on image-like inputs,
+# 8.0e-5 on iid, coarser scales 1.2e-4 .. 7.5e-4 -- and the allowance was cut to 3e-4 (1.8e-3): ~4x / 2.4x the largest measured
+HOT_PATH_BAD_SHARE = 3e-4
+HOT_PATH_BAD_SHARE_COARSE_FACTOR = 6
 ENTRYWISE_MAX_FACTOR = {"smooth": 4.0, "iid": 4.0, "scene": 4.0}
 # Round 5: the iid bound was 10 (measured 3.6 .. 6.6).  tools/diag_gates.py traced the 20 worst judged entries of every map
 # (profiles/r05_iid_worst_entries.json): all of them pixels whose VALUE gates -- sign / clamp of the depth inconsistency,
@@ -221,12 +228,14 @@ def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto, 
         # (one seed, a handful of rows: the median only; the distribution over four seeds -- median, 90 % quantile and
         # maximum against the reference's own fp32 arithmetic -- is test_iid_pose_gradients_as_row_statistics_over_seeds)
         assert float(rows_h.median()) <= IID_ROW_FACTOR * float(rows_o.median()) + POSE_RTOL, (rows_h, rows_o)
+    worst_bad = [0.0, 0.0]  # (full-resolution maps, coarser scales' maps)
     for i, (a, b, c) in enumerate(zip(gh, go, g64)):
         scale = float(c.abs().max())
         if i <= n_ref or i > 3 * n_ref:   # depth maps: entry-wise with a small share of outliers (flipped pixels)
             assert a.shape == b.shape
             bad = ((a - b).abs() > 5e-3 * scale).double().mean().item()
-            assert bad <= 2e-3 * (1 if i <= n_ref else 4), (i, bad)  # (a coarse entry pools up to 64 pixels' flips)
+            worst_bad[0 if i <= n_ref else 1] = max(worst_bad[0 if i <= n_ref else 1], bad)
+            assert bad <= HOT_PATH_BAD_SHARE * (1 if i <= n_ref else HOT_PATH_BAD_SHARE_COARSE_FACTOR), (i, bad)
         elif depth == "iid":
             continue
         else:            # poses: every entry, noise-aware
@@ -238,6 +247,8 @@ def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto, 
             # entries: also accept being no further from fp64 than 1.5 x the reference's own worst entry
             tensorwise = float((a - c).abs().max()) <= POSE_RTOL * scale + 1.5 * float(ref_noise.max())
             assert entrywise or tensorwise, (i, float((a - c).abs().max()), float(ref_noise.max()), scale)
+    report(f"hot path vs oracle [{dataset} {B}x{H}x{W} refs {n_ref} {depth} auto {auto} {pad} scales {scales}]: share of depth-gradient entries "
+           f"where HIP fp32 and the oracle's fp32 differ by > 0.5 % of scale: {worst_bad[0]:.2e}" + (f" (coarser scales: {worst_bad[1]:.2e})" if scales > 1 else ""))
 
 
 def test_forward_only_validation_path_against_oracle(LF, dev):
