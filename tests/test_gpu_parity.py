@@ -229,6 +229,7 @@ def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto, 
         # maximum against the reference's own fp32 arithmetic -- is test_iid_pose_gradients_as_row_statistics_over_seeds)
         assert float(rows_h.median()) <= IID_ROW_FACTOR * float(rows_o.median()) + POSE_RTOL, (rows_h, rows_o)
     worst_bad = [0.0, 0.0]  # (full-resolution maps, coarser scales' maps)
+    pose_need, pose_hip, pose_ref = -1.0, 0.0, 0.0
     for i, (a, b, c) in enumerate(zip(gh, go, g64)):
         scale = float(c.abs().max())
         if i <= n_ref or i > 3 * n_ref:   # depth maps: entry-wise with a small share of outliers (flipped pixels)
@@ -247,6 +248,13 @@ def test_hot_path_against_oracle(LF, dev, B, H, W, n_ref, dataset, depth, auto, 
             # entries: also accept being no further from fp64 than 1.5 x the reference's own worst entry
             tensorwise = float((a - c).abs().max()) <= POSE_RTOL * scale + 1.5 * float(ref_noise.max())
             assert entrywise or tensorwise, (i, float((a - c).abs().max()), float(ref_noise.max()), scale)
+            # what the entry-wise bound needs of its constant term: max over the entries of (|hip - fp64| - 4 |fp32 ref - fp64|) / scale
+            pose_need = max(pose_need, float((((a - c).abs() - 4 * ref_noise) / scale).max()))
+            pose_hip = max(pose_hip, float((a - c).abs().max()) / scale)
+            pose_ref = max(pose_ref, float(ref_noise.max()) / scale)
+    if depth != "iid":
+        report(f"hot path vs oracle [{dataset} {B}x{H}x{W} refs {n_ref} {depth} auto {auto} {pad} scales {scales}]: pose gradients, worst entry / tensor scale: "
+               f"hip {pose_hip:.2e}, reference fp32 arithmetic {pose_ref:.2e}; constant the noise-aware bound needs: {max(pose_need, 0.0):.2e} (allowed {POSE_RTOL:.1e})")
     report(f"hot path vs oracle [{dataset} {B}x{H}x{W} refs {n_ref} {depth} auto {auto} {pad} scales {scales}]: share of depth-gradient entries "
            f"where HIP fp32 and the oracle's fp32 differ by > 0.5 % of scale: {worst_bad[0]:.2e}" + (f" (coarser scales: {worst_bad[1]:.2e})" if scales > 1 else ""))
 
