@@ -189,3 +189,59 @@ def test_seeded_shapes_of_the_other_callables_on_the_hardware(case):
     from scsfm_hip import _lib
     assert _lib.get().path.endswith("libscsfm_hip.so")
     _run_aux_case(LF, IW, case, torch.device("cuda:0"))
+
+
+# ---- tensors as a caller may hand them over: the reference is plain torch and takes any strides (images of a channels_last
+# net, a depth map that is one channel of a wider tensor, an expanded intrinsics matrix); the drop-in must give the same
+# numbers as for their contiguous copies
+def _run_strided_case(LF, device, dtype):
+    B, H, W = 3, 47, 67
+    d = synth.make_batch(B, H, W, n_ref=2, seed=77, depth="smooth")
+    c = lambda x: x.to(device=device, dtype=dtype).contiguous()
+
+    def strided_depth(x):  # [B,1,H,W] as channel 1 of a [B,3,H,W] tensor
+        wide = torch.zeros(B, 3, H, W, dtype=dtype, device=device)
+        wide[:, 1:2] = c(x)
+        return wide[:, 1:2]
+
+    def run(img_f, depth_f, K_f):
+        td = [depth_f(d["tgt_depth"][0]).detach().requires_grad_(True)]
+        rd = [[depth_f(r[0]).detach().requires_grad_(True)] for r in d["ref_depths"]]
+        ps = [c(p).requires_grad_(True) for p in d["poses"]]
+        pi = [c(p).requires_grad_(True) for p in d["poses_inv"]]
+        tgt, refs = img_f(d["tgt_img"]), [img_f(r) for r in d["ref_imgs"]]
+        photo, geom = LF.compute_photo_and_geometry_loss(tgt, refs, K_f(d["intrinsics"]), td, rd, ps, pi, 1, 1, 1, 1, "zeros")
+        smooth = LF.compute_smooth_loss(td, tgt, rd, refs)
+        (photo + 0.1 * smooth + 0.5 * geom).backward()
+        return ([float(photo.detach()), float(geom.detach()), float(smooth.detach())],
+                [t.grad.detach().cpu() for t in td + [r[0] for r in rd] + ps + pi])
+
+    v0, g0 = run(c, c, c)
+    nhwc = lambda x: c(x).contiguous(memory_format=torch.channels_last)
+    expanded_K = lambda K: c(K)[:1].expand(B, 3, 3) if bool((K == K[:1]).all()) else c(K).transpose(1, 2).contiguous().transpose(1, 2)
+    v1, g1 = run(nhwc, strided_depth, expanded_K)
+    assert not nhwc(d["tgt_img"]).is_contiguous() and not strided_depth(d["tgt_depth"][0]).is_contiguous()
+    assert v0 == v1, (v0, v1)  # the same kernels on the same values: bit for bit
+    tol = 1e-12 if dtype == torch.float64 else 2e-5  # (fp32: the scatter's atomics may arrive in another order)
+    for a, b in zip(g0, g1):
+        assert a.shape == b.shape and _rel(b, a) <= tol
+
+
+def test_strided_inputs_give_the_numbers_of_their_contiguous_copies_on_the_simulator(monkeypatch):
+    import loss_functions as LF
+    from hostsim import harness
+    from scsfm_hip import _lib, ops
+    lib = harness.lib()
+    monkeypatch.setattr(_lib, "get", lambda: lib)
+    monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)
+    _run_strided_case(LF, torch.device("cpu"), torch.float64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_strided_inputs_give_the_numbers_of_their_contiguous_copies_on_the_hardware(dtype):
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import loss_functions as LF
+    from scsfm_hip import _lib
+    assert _lib.get().path.endswith("libscsfm_hip.so")
+    _run_strided_case(LF, torch.device("cuda:0"), dtype)
